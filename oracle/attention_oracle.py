@@ -1,0 +1,278 @@
+"""CPU oracle for the FlashAttention forward/backward hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package
+(`flashattention-pytorch_amd/`) may import this module; only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do, and
+there only as the checker / the timed CPU baseline.
+
+Parity status: PINNED.  `tests/golden/*.npz` were produced in the build
+container by importing the reference's own Python
+(`/root/reference/src/common/correctness.py`, `src/fa1/torch/impl.py`) with
+`tests/golden/make_golden.py`; `tests/test_oracle_golden.py` checks every
+function below against those vectors.
+
+What is restated (reference file:line, paths relative to /root/reference):
+
+* `exact_attention`            <- `src/common/correctness.py:5-24`
+      (`reference_attention`): fp32 scores = QK^T * scale, causal mask
+      col > row -> -inf (`src/common/mask.py:6-12`), softmax, P@V cast back to
+      the input dtype, lse = logsumexp (natural log, fp32).
+      The reference's causal branch is broken for 3-D input (the
+      mask helper reads shape[0], shape[1] of a (BH, N, N) tensor); this
+      restatement applies the mask per (b,h) slice, which is what the helper
+      does on the 2-D tiles it was written for.
+* `exact_attention_backward`   <- `src/common/correctness.py:26-34`
+      (`reference_backward`): autograd of the above with `o.backward(do)`.
+      Written here in closed form (no autograd) in fp32 or fp64.
+* `tiled_forward`              <- `src/fa1/torch/impl.py:26-68`
+      (`fa1_forward_torch`): Q-tile outer / K-tile inner online softmax with
+      un-normalised O until the epilogue.
+* `tiled_backward`             <- `src/fa1/torch/impl.py:70-115`
+      (`fa1_backward_torch`): dvec = rowsum(dO*O); K-tile outer / Q-tile inner
+      recomputation from lse.
+  The FA2 torch/csrc variants (`src/fa2/torch/impl.py:57,62,107-112`,
+  `csrc/fa2/fa2_fwd.cu:92-99`, `csrc/fa?/fa?_bwd.cu:80`) carry the numeric
+  defects listed in SURVEY §4.3 (D2-D4) and are NOT followed: FA1, FA2 and FA3
+  are the same mathematical function and the correct statement is FA1's.
+* `block_absmax_scale`, `quantize_e4m3_blockwise`
+                               <- intent of `src/fa3/torch/impl.py:20-44`
+      (per-block absmax scale, eps 1e-6, block = br for Q / bc for K).  The
+      reference's "fp8" is an fp16 round trip; the oracle models a
+      real OCP e4m3 quantisation, which is what the HIP fp8 path does.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+__all__ = [
+    "exact_attention",
+    "exact_attention_backward",
+    "tiled_forward",
+    "tiled_backward",
+    "block_absmax_scale",
+    "quantize_e4m3_blockwise",
+    "fp8_attention",
+    "attention_flops",
+]
+
+
+def _as3d(x: torch.Tensor) -> Tuple[torch.Tensor, Optional[Tuple[int, int]]]:
+    # (B,H,N,d) -> (BH,N,d) view; reference: src/common/utils.py:3-7
+    if x.dim() == 3:
+        return x, None
+    b, h, n, d = x.shape
+    return x.reshape(b * h, n, d), (b, h)
+
+
+def _causal_mask(n_q: int, n_k: int, device) -> torch.Tensor:
+    r = torch.arange(n_q, device=device)[:, None]
+    c = torch.arange(n_k, device=device)[None, :]
+    return c > r  # True = masked; reference: src/common/mask.py:9-11
+
+
+def exact_attention(q, k, v, causal=False, softmax_scale=None, math_dtype=torch.float32):
+    """Dense attention. Returns (o in q.dtype, lse fp32). Shapes follow the input rank."""
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** -0.5
+    qb, bh_shape = _as3d(q)
+    kb, _ = _as3d(k)
+    vb, _ = _as3d(v)
+    n = qb.shape[1]
+    s = torch.matmul(qb.to(math_dtype), kb.to(math_dtype).transpose(-2, -1)) * softmax_scale
+    if causal:
+        s = s.masked_fill(_causal_mask(n, kb.shape[1], s.device)[None], float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse[..., None])
+    o = torch.matmul(p, vb.to(math_dtype)).to(q.dtype)
+    lse = lse.to(torch.float32)
+    if bh_shape is not None:
+        b, h = bh_shape
+        o = o.reshape(b, h, n, -1)
+        lse = lse.reshape(b, h, n)
+    return o, lse
+
+
+def exact_attention_backward(q, k, v, do, causal=False, softmax_scale=None, math_dtype=torch.float32):
+    """Closed-form gradient of `exact_attention`'s `o` w.r.t. q, k, v for upstream `do`.
+
+    Matches what autograd gives for `o.backward(do)` in the reference
+    (`src/common/correctness.py:26-34`): the output cast to q.dtype is treated
+    as identity, the gradients are returned in the input dtype.
+    Returns (dq, dk, dv, o, lse).
+    """
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** -0.5
+    qb, bh_shape = _as3d(q)
+    kb, _ = _as3d(k)
+    vb, _ = _as3d(v)
+    dob, _ = _as3d(do)
+    n = qb.shape[1]
+    qf, kf, vf, dof = (t.to(math_dtype) for t in (qb, kb, vb, dob))
+    s = torch.matmul(qf, kf.transpose(-2, -1)) * softmax_scale
+    if causal:
+        s = s.masked_fill(_causal_mask(n, kf.shape[1], s.device)[None], float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse[..., None])
+    of = torch.matmul(p, vf)
+    dv = torch.matmul(p.transpose(-2, -1), dof)
+    dp = torch.matmul(dof, vf.transpose(-2, -1))
+    delta = (dof * of).sum(dim=-1, keepdim=True)
+    ds = p * (dp - delta)
+    dq = torch.matmul(ds, kf) * softmax_scale
+    dk = torch.matmul(ds.transpose(-2, -1), qf) * softmax_scale
+    o = of.to(q.dtype)
+    dq, dk, dv = dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype)
+    lse = lse.to(torch.float32)
+    if bh_shape is not None:
+        b, h = bh_shape
+        dq, dk, dv, o = (t.reshape(b, h, n, -1) for t in (dq, dk, dv, o))
+        lse = lse.reshape(b, h, n)
+    return dq, dk, dv, o, lse
+
+
+def tiled_forward(q, k, v, causal, softmax_scale, br, bc):
+    """Online-softmax tile loop over (bh, Q tile, K tile); q,k,v are (BH,N,d).
+
+    Follows `src/fa1/torch/impl.py:26-68`, with one deliberate difference: the
+    causal mask is applied to every tile that intersects the diagonal, not only
+    when the tile's first row lies inside the column tile (the reference's
+    condition at :50 is correct only for br <= bc).
+    """
+    bh, n, d = q.shape
+    o = torch.empty_like(q)
+    lse = torch.empty((bh, n), dtype=torch.float32, device=q.device)
+    for b in range(bh):
+        for r0 in range(0, n, br):
+            r1 = min(r0 + br, n)
+            qi = q[b, r0:r1].float()
+            m = torch.full((r1 - r0,), float("-inf"))
+            l = torch.zeros(r1 - r0)
+            acc = torch.zeros(r1 - r0, d)
+            for c0 in range(0, n, bc):
+                if causal and c0 >= r1:  # whole tile above the diagonal
+                    break
+                c1 = min(c0 + bc, n)
+                s = (qi @ k[b, c0:c1].float().T) * softmax_scale
+                if causal and c1 - 1 > r0:  # tile touches the diagonal
+                    rr = torch.arange(r0, r1)[:, None]
+                    cc = torch.arange(c0, c1)[None, :]
+                    s = s.masked_fill(cc > rr, float("-inf"))
+                m_new = torch.maximum(m, s.amax(dim=-1))
+                p = torch.exp(s - m_new[:, None])
+                alpha = torch.exp(m - m_new)
+                l = alpha * l + p.sum(dim=-1)
+                acc = alpha[:, None] * acc + p @ v[b, c0:c1].float()
+                m = m_new
+            o[b, r0:r1] = (acc / l[:, None]).to(q.dtype)
+            lse[b, r0:r1] = m + torch.log(l)
+    return o, lse
+
+
+def tiled_backward(q, k, v, o, do, lse, causal, softmax_scale, br, bc):
+    """Recomputation backward, K tile outer / Q tile inner (`src/fa1/torch/impl.py:70-115`)."""
+    bh, n, d = q.shape
+    dq = torch.zeros(bh, n, d)
+    dk = torch.zeros(bh, n, d)
+    dv = torch.zeros(bh, n, d)
+    delta = (do.float() * o.float()).sum(dim=-1)
+    for b in range(bh):
+        for c0 in range(0, n, bc):
+            c1 = min(c0 + bc, n)
+            kj = k[b, c0:c1].float()
+            vj = v[b, c0:c1].float()
+            dkj = torch.zeros(c1 - c0, d)
+            dvj = torch.zeros(c1 - c0, d)
+            for r0 in range(0, n, br):
+                r1 = min(r0 + br, n)
+                if causal and c0 >= r1:  # every (row, col) of this pair is masked
+                    continue
+                qi = q[b, r0:r1].float()
+                doi = do[b, r0:r1].float()
+                s = (qi @ kj.T) * softmax_scale
+                if causal and c1 - 1 > r0:
+                    rr = torch.arange(r0, r1)[:, None]
+                    cc = torch.arange(c0, c1)[None, :]
+                    s = s.masked_fill(cc > rr, float("-inf"))
+                p = torch.exp(s - lse[b, r0:r1, None])
+                dvj += p.T @ doi
+                dp = doi @ vj.T
+                ds = p * (dp - delta[b, r0:r1, None])
+                dq[b, r0:r1] += (ds @ kj) * softmax_scale
+                dkj += (ds.T @ qi) * softmax_scale
+            dk[b, c0:c1] = dkj
+            dv[b, c0:c1] = dvj
+    return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype)
+
+
+# --------------------------------------------------------------------------- fp8 (FA3-style) model
+
+
+def block_absmax_scale(x: torch.Tensor, block: int, eps: float = 1e-6) -> torch.Tensor:
+    """Per (bh, row-block) absmax, clamped below by eps (`src/fa3/torch/impl.py:20-31`)."""
+    bh, n, d = x.shape
+    nb = (n + block - 1) // block
+    out = torch.empty(bh, nb, dtype=torch.float32)
+    for i in range(nb):
+        blk = x[:, i * block : min((i + 1) * block, n)].float()
+        out[:, i] = blk.abs().amax(dim=(1, 2)).clamp_min(eps)
+    return out
+
+
+E4M3_MAX = 448.0
+
+
+def quantize_e4m3_blockwise(x: torch.Tensor, block: int):
+    """Quantise to OCP e4m3 with one scale per (bh, row block): x ~= xq * scale.
+
+    scale = absmax / 448 so the block's largest element maps to the e4m3
+    maximum.  Returns (xq as float32 holding exactly-representable e4m3 values,
+    scale (bh, nb) fp32).
+    """
+    bh, n, d = x.shape
+    amax = block_absmax_scale(x, block)
+    scale = amax / E4M3_MAX
+    xq = torch.empty(bh, n, d, dtype=torch.float32)
+    for i in range(amax.shape[1]):
+        sl = slice(i * block, min((i + 1) * block, n))
+        y = x[:, sl].float() / scale[:, i, None, None]
+        xq[:, sl] = y.to(torch.float8_e4m3fn).float()
+    return xq, scale
+
+
+def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k):
+    """Attention with Q and K quantised to e4m3 per row block, V and P kept in 16/32-bit.
+
+    This is the numerical model of the HIP `fa3_forward(fp8=True)` path.
+    """
+    qq, sq = quantize_e4m3_blockwise(q, block_q)
+    kq, sk = quantize_e4m3_blockwise(k, block_k)
+    n = q.shape[1]
+    rq = torch.repeat_interleave(sq, block_q, dim=1)[:, :n]
+    rk = torch.repeat_interleave(sk, block_k, dim=1)[:, :n]
+    qd = qq * rq[..., None]
+    kd = kq * rk[..., None]
+    return exact_attention(qd.to(q.dtype).float(), kd.to(k.dtype).float(), v.float(), causal, softmax_scale)
+
+
+# --------------------------------------------------------------------------- FLOP accounting
+
+
+def attention_flops(bh: int, n: int, d: int, direction: str, causal: bool = False, convention: str = "algorithmic"):
+    """FLOPs of one pass.
+
+    convention="algorithmic": fwd 4*N^2*d, bwd 10*N^2*d (5 GEMMs), fwd+bwd 14*N^2*d,
+    causal scaled by (N+1)/(2N)  (SURVEY §8d).
+    convention="reference": `benchmarks/bench_utils.py:210-215` — forward 4*B*H*N^2*d,
+    "backward" (= fwd+bwd timed together) 8*B*H*N^2*d, no causal discount.
+    """
+    if convention == "reference":
+        factor = 4.0 if direction == "forward" else 8.0
+        return factor * bh * n * n * d
+    factor = {"forward": 4.0, "backward": 10.0, "fwd+bwd": 14.0}[direction]
+    f = factor * bh * n * n * d
+    if causal:
+        f *= (n + 1) / (2.0 * n)
+    return f
