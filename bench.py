@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — attention fwd+bwd TFLOP/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward + one backward of FA2 attention over the rank's shard of (b,h) units, through the
+reference-shaped wrapper (`fa2_cuda` autograd Function -> ctypes -> C-ABI -> HIP kernels), with q, k, v and dO
+already resident in HBM.  Workload (default): BASELINE.json config 4's per-GPU shard, B=8 H=32 N=4096 d=128
+bf16 non-causal = 256 independent (b,h) units per GPU; with N ranks every rank owns 256 units (weak scaling,
+N=8 is config 4 exactly: B=64 H=32) and there is no collective on the data path.  The final RCCL all-gather of
+o/dq/dk/dv that would rebuild the full (B,H,N,d) tensors on every rank is timed separately ("gather_ms").
+
+Prints ONE JSON line on rank 0 (fields: see the driver contract) including
+  "roofline":     dominant kernel, algorithmic FLOPs per launch / HIP-event kernel time, vs 2.5 PFLOP/s dense bf16
+  "cpu_baseline": the CPU oracle's tile loops (oracle/attention_oracle.py, a restatement of the reference's
+                  src/fa1/torch/impl.py) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "flashattention-pytorch_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+
+
+def alg_flops(bh, n, d, causal, direction):
+    f = {"fwd": 4.0, "bwd": 10.0, "fwd+bwd": 14.0}[direction] * bh * n * n * d
+    return f * ((n + 1) / (2.0 * n) if causal else 1.0)
+
+
+def cpu_baseline(n, d, dtype, causal, budget_s):
+    """Time the oracle's tiled fwd+bwd (the reference's CPU path restated) on a bounded number of (b,h) units."""
+    from oracle import attention_oracle as orc
+    from fa2.spec import pick_fa2_spec
+
+    spec = pick_fa2_spec(d)
+    g = torch.Generator().manual_seed(0)
+    units, elapsed = 0, 0.0
+    t_all = time.perf_counter()
+    while True:
+        q, k, v, do = (torch.randn((1, n, d), generator=g).to(dtype) for _ in range(4))
+        t0 = time.perf_counter()
+        o, lse = orc.tiled_forward(q, k, v, causal, d ** -0.5, spec.br, spec.bc)
+        orc.tiled_backward(q, k, v, o, do, lse, causal, d ** -0.5, spec.br, spec.bc)
+        elapsed += time.perf_counter() - t0
+        units += 1
+        if time.perf_counter() - t_all > budget_s or units >= 64:
+            break
+    tflops = alg_flops(units, n, d, causal, "fwd+bwd") / elapsed / 1e12
+    return {
+        "value": round(tflops, 5), "unit": "TFLOP/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{units} of the (b,h) units of the same workload (N={n}, d={d}, {'causal' if causal else 'non-causal'}), "
+                  f"oracle tiled_forward+tiled_backward (br={spec.br}, bc={spec.bc}), {elapsed:.1f} s of CPU time, "
+                  f"host has {os.cpu_count()} logical cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="batch per GPU")
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--seqlen", type=int, default=4096)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=list(DT))
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the separately timed RCCL all-gather")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    import flashattention_lab_cuda as ext
+    from fa2.cuda.impl import fa2_cuda
+    from fa2.spec import pick_fa2_spec
+
+    B, H, N, D = args.batch, args.heads, args.seqlen, args.head_dim
+    dtype = DT[args.dtype]
+    bh = B * H  # units owned by this rank
+    spec = pick_fa2_spec(D)
+    scale = D ** -0.5
+    g = torch.Generator(device=dev)
+    g.manual_seed(rank)  # benchmarks/bench_utils.py:83-97 order q, k, v (+ dO)
+    q, k, v = (torch.randn((B, H, N, D), device=dev, dtype=dtype, generator=g).requires_grad_(True) for _ in range(3))
+    do = torch.randn((B, H, N, D), device=dev, dtype=dtype, generator=g)
+
+    def step():
+        q.grad = k.grad = v.grad = None
+        o, _ = fa2_cuda(q, k, v, args.causal, scale, spec)
+        torch.autograd.backward(o, do)
+        return o
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- per-kernel durations (HIP events on the launch stream, inside the library), separate untimed pass
+    ext.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = ext.profile_report()
+    ext.profile_enable(False)
+
+    # ---- separately timed RCCL all-gather of the outputs (rebuilds the full (B*world,H,N,d) tensors)
+    gather_ms = None
+    if dist is not None and not args.no_gather:
+        outs = [o.detach(), q.grad, k.grad, v.grad]
+        full = [torch.empty((world,) + t.shape, device=dev, dtype=t.dtype) for t in outs]
+        for rep in range(3):
+            torch.cuda.synchronize(); barrier(); t1 = time.perf_counter()
+            for t, f in zip(outs, full):
+                dist.all_gather_into_tensor(f, t.contiguous())
+            torch.cuda.synchronize(); barrier()
+            gather_ms = (time.perf_counter() - t1) * 1e3
+        tg = torch.tensor([gather_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = tg.item()
+
+    if rank == 0:
+        total_flops = alg_flops(bh * world, N, D, args.causal, "fwd+bwd") * args.steps
+        value = total_flops / elapsed / 1e12
+        # dominant kernel = the one with the largest total event time
+        kern = max(prof, key=lambda kname: prof[kname][1]) if prof else None
+        roof = None
+        if kern is not None:
+            cnt, tot_ms = prof[kern]
+            direction = "fwd" if kern.startswith("fwd") else "bwd"
+            per_launch = alg_flops(bh, N, D, args.causal, direction)
+            if kern in ("bwd_dkdv_f32", "bwd_dq_f32"):
+                per_launch *= 0.5  # the exact-f32 backward is split in two kernels; each is priced at half of 10*N^2*d
+            ach = per_launch / (tot_ms / cnt * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.dtype]
+            roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(tot_ms / cnt, 4),
+                    "algorithmic_flop_per_launch": per_launch,
+                    "kernels_ms_per_step": {kname: round(v_[1] / max(1, args.steps), 4) for kname, v_ in prof.items()}}
+        cpu = None
+        if args.cpu_seconds > 0:
+            cpu = cpu_baseline(N, D, dtype, args.causal, args.cpu_seconds)
+        line = {
+            "metric": "attention fwd+bwd TFLOP/s (algorithmic 14*N^2*d per (b,h)), N=%d d=%d" % (N, D),
+            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"FA2 fwd+bwd B={B}x{world} H={H} N={N} d={D} {args.dtype} "
+                                   f"{'causal' if args.causal else 'non-causal'} (BASELINE config 4 shard: 256 (b,h) units per GPU)",
+                       "global_batch": B * world, "heads": H, "seq_len": N, "head_dim": D, "causal": args.causal,
+                       "parallelism": f"(b,h)-shard x{world}, no data-path collective"},
+            "per_gpu_tflops": round(value / world, 2),
+            "frac_of_peak_per_gpu": round(value / world / PEAK_TFLOPS[args.dtype], 4),
+            "reference_convention_tflops": round(8.0 * bh * world * N * N * D * args.steps / elapsed / 1e12, 2),
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,237 @@
+// C-ABI entry points declared in include/fa_mi355x.h: argument validation, kernel dispatch,
+// error reporting.  No torch types, no allocation, no device synchronisation: everything is
+// enqueued on the caller's stream.
+#include "../../include/fa_mi355x.h"
+#include "fa_kernels.h"
+
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::atomic<int> g_mode{FA_MODE_AUTO};
+
+// ---- per-kernel event timing -------------------------------------------------------------------
+struct ProfRec { int id; hipEvent_t a, b; };
+std::atomic<int> g_prof_on{0};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_free;
+hipEvent_t g_prof_open[fa::K_COUNT];
+const char* const kKernelNames[fa::K_COUNT] = {"fwd_f32", "bwd_delta", "bwd_dkdv_f32", "bwd_dq_f32", "fwd_mfma",
+                                               "bwd_mfma", "bwd_dq_cvt", "fp8_quant", "fwd_fp8"};
+
+hipEvent_t prof_get_event() {
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_common(const char* who, int64_t bh, int64_t n, int64_t d, int dtype, double scale) {
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_F16 && dtype != FA_DTYPE_BF16)
+        return fail(FA_ERR_INVALID_ARGUMENT, "%s: unknown dtype code %d", who, dtype);
+    if (bh < 0 || n < 0 || d <= 0)
+        return fail(FA_ERR_INVALID_ARGUMENT, "%s: bad shape (BH=%lld, N=%lld, d=%lld)", who, (long long)bh, (long long)n,
+                    (long long)d);
+    if (d > 256) return fail(FA_ERR_UNSUPPORTED, "%s: head_dim %lld > 256 is not supported", who, (long long)d);
+    if (n > (int64_t)1 << 24) return fail(FA_ERR_UNSUPPORTED, "%s: N=%lld too large", who, (long long)n);
+    if (bh * ((n + 63) / 64) >= ((int64_t)1 << 31))
+        return fail(FA_ERR_UNSUPPORTED, "%s: BH*N too large for one launch", who);
+    if (!(scale == scale)) return fail(FA_ERR_INVALID_ARGUMENT, "%s: softmax_scale is NaN", who);
+    return FA_OK;
+}
+
+bool use_mfma_fwd(int dtype, int64_t d) { return g_mode.load() == FA_MODE_AUTO && fa::fwd_mfma_supported(dtype, d); }
+bool use_mfma_bwd(int dtype, int64_t d) { return g_mode.load() == FA_MODE_AUTO && fa::bwd_mfma_supported(dtype, d); }
+
+int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
+                 int64_t n, int64_t d, int dtype, int causal, double scale, void* stream) {
+    int rc = check_common(who, bh, n, d, dtype, scale);
+    if (rc != FA_OK) return rc;
+    if (bh == 0 || n == 0) return FA_OK;  // empty problem: nothing to write
+    if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", who);
+    fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)scale};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = use_mfma_fwd(dtype, d) ? fa::launch_fwd_mfma(a, st) : fa::launch_fwd_generic(a, st);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
+    return FA_OK;
+}
+
+int backward_impl(const char* who, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                  const float* lse, void* dq, void* dk, void* dv, int64_t bh, int64_t n, int64_t d, int dtype,
+                  int causal, double scale, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(who, bh, n, d, dtype, scale);
+    if (rc != FA_OK) return rc;
+    if (bh == 0 || n == 0) return FA_OK;
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv)
+        return fail(FA_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", who);
+    const size_t need = fa_backward_workspace_bytes(bh, n, d, dtype);
+    if (!ws || ws_bytes < need)
+        return fail(FA_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, ws_bytes);
+    fa::BwdArgs a{q, k, v, o, dout, lse, dq, dk, dv, bh, n, d, dtype, causal ? 1 : 0, (float)scale, ws, ws_bytes};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = use_mfma_bwd(dtype, d) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
+    return FA_OK;
+}
+
+}  // namespace
+
+namespace fa {
+void prof_begin(int id, hipStream_t st) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = prof_get_event();
+    (void)hipEventRecord(e, st);
+    g_prof_open[id] = e;
+}
+void prof_end(int id, hipStream_t st) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = prof_get_event();
+    (void)hipEventRecord(e, st);
+    g_prof_recs.push_back(ProfRec{id, g_prof_open[id], e});
+}
+}  // namespace fa
+
+extern "C" {
+
+int fa_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) { g_prof_free.push_back(r.a); g_prof_free.push_back(r.b); }
+    g_prof_recs.clear();
+    return g_prof_on.exchange(on ? 1 : 0);
+}
+
+// Waits for the recorded events and writes "name count total_ms\n" lines for every kernel launched since
+// fa_profile_enable(1). Returns the number of bytes written (excluding the NUL), or a negative error code.
+int fa_profile_report(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double total[fa::K_COUNT] = {0};
+    long count[fa::K_COUNT] = {0};
+    for (auto& r : g_prof_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_profile_report: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_profile_report: elapsed failed");
+        total[r.id] += ms;
+        count[r.id] += 1;
+    }
+    std::string out;
+    char line[128];
+    for (int i = 0; i < fa::K_COUNT; ++i) {
+        if (!count[i]) continue;
+        snprintf(line, sizeof(line), "%s %ld %.6f\n", kKernelNames[i], count[i], total[i]);
+        out += line;
+    }
+    if (!buf || cap == 0) return (int)out.size();
+    const size_t nw = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), nw);
+    buf[nw] = 0;
+    return (int)nw;
+}
+
+int fa1_forward(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int64_t d,
+                int dtype, int causal, double softmax_scale, int64_t br, int64_t bc, void* stream) {
+    (void)br; (void)bc;  // tile hints: results are tile independent (SURVEY §8b "Tile params")
+    return forward_impl("fa1_forward", q, k, v, o, lse, bh, n, d, dtype, causal, softmax_scale, stream);
+}
+
+int fa1_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv, int64_t bh, int64_t n, int64_t d, int dtype, int causal,
+                 double softmax_scale, int64_t br, int64_t bc, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)br; (void)bc;
+    return backward_impl("fa1_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
+                         workspace, workspace_bytes, stream);
+}
+
+int fa2_forward(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int64_t d,
+                int dtype, int causal, double softmax_scale, int64_t br, int64_t bc, void* stream) {
+    (void)br; (void)bc;
+    return forward_impl("fa2_forward", q, k, v, o, lse, bh, n, d, dtype, causal, softmax_scale, stream);
+}
+
+int fa2_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv, int64_t bh, int64_t n, int64_t d, int dtype, int causal,
+                 double softmax_scale, int64_t br, int64_t bc, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)br; (void)bc;
+    return backward_impl("fa2_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
+                         workspace, workspace_bytes, stream);
+}
+
+int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t n, int64_t d,
+                int dtype, int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
+                void* workspace, size_t workspace_bytes, void* stream) {
+    (void)br; (void)bc; (void)stages;
+    if (fp8) {
+        int rc = check_common("fa3_forward", bh, n, d, dtype, softmax_scale);
+        if (rc != FA_OK) return rc;
+        if (!fa::fwd_fp8_supported(dtype, d))
+            return fail(FA_ERR_UNSUPPORTED, "fa3_forward: fp8=True needs f16/bf16 tensors and head_dim 64 or 128 (got dtype %d, d=%lld)",
+                        dtype, (long long)d);
+        if (bh == 0 || n == 0) return FA_OK;
+        if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_forward: null tensor pointer");
+        const size_t need = fa3_forward_workspace_bytes(bh, n, d, dtype, 1);
+        if (!workspace || workspace_bytes < need)
+            return fail(FA_ERR_WORKSPACE, "fa3_forward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
+        hipError_t e = fa::launch_fwd_fp8(a, workspace, reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_forward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+        return FA_OK;
+    }
+    return forward_impl("fa3_forward", q, k, v, o, lse, bh, n, d, dtype, causal, softmax_scale, stream);
+}
+
+int fa3_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv, int64_t bh, int64_t n, int64_t d, int dtype, int causal,
+                 double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    (void)br; (void)bc; (void)stages; (void)fp8;  // straight-through: gradient of the un-quantised function
+    return backward_impl("fa3_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
+                         workspace, workspace_bytes, stream);
+}
+
+size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype) {
+    if (bh <= 0 || n <= 0 || d <= 0) return 256;
+    size_t g = fa::bwd_generic_workspace_bytes(bh, n);
+    size_t m = fa::bwd_mfma_supported(dtype, d) ? fa::bwd_mfma_workspace_bytes(bh, n, d) : 0;
+    size_t need = g > m ? g : m;
+    return (need + 255) & ~(size_t)255;
+}
+
+size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
+    if (!fp8 || bh <= 0 || n <= 0 || d <= 0) return 0;
+    (void)dtype;
+    return fa::fwd_fp8_workspace_bytes(bh, n, d);
+}
+
+const char* fa_last_error(void) { return g_err; }
+const char* fa_version(void) { return "fa_mi355x 0.1.0 (gfx950)"; }
+
+int fa_set_kernel_mode(int mode) {
+    if (mode != FA_MODE_AUTO && mode != FA_MODE_F32_GENERIC) return fail(FA_ERR_INVALID_ARGUMENT, "fa_set_kernel_mode: bad mode %d", mode);
+    return g_mode.exchange(mode);
+}
+
+int fa_device_is_gfx950(int device) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Shared device helpers for the gfx950 FlashAttention kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// ---- scalar element conversion (generic path) ----
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half x) { return __half2float(x); }
+template <> __device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 x) { return __bfloat162float(x); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float x) { return __float2half_rn(x); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
+
+// ---- packed 16-bit conversion (fast path); returns two 16-bit values in one dword, lo in bits 0..15 ----
+template <typename Tag> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_tag>(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t pack2<f16_tag>(float lo, float hi) {
+    __half2 v = __floats2half2_rn(lo, hi);
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+// round-to-nearest-even variant for values that are stored as results
+template <typename Tag> __device__ __forceinline__ uint32_t pack2_rn(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2_rn<bf16_tag>(float lo, float hi) { return pack2<bf16_tag>(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2_rn<f16_tag>(float lo, float hi) {
+    __half2 v = __floats2half2_rn(lo, hi);
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
+template <typename Tag> __device__ __forceinline__ float unpack_lo(uint32_t v);
+template <typename Tag> __device__ __forceinline__ float unpack_hi(uint32_t v);
+template <> __device__ __forceinline__ float unpack_lo<bf16_tag>(uint32_t v) { return __uint_as_float(v << 16); }
+template <> __device__ __forceinline__ float unpack_hi<bf16_tag>(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+template <> __device__ __forceinline__ float unpack_lo<f16_tag>(uint32_t v) {
+    return __half2float(__ushort_as_half((unsigned short)(v & 0xffffu)));
+}
+template <> __device__ __forceinline__ float unpack_hi<f16_tag>(uint32_t v) {
+    return __half2float(__ushort_as_half((unsigned short)(v >> 16)));
+}
+
+// ---- MFMA wrappers: 32x32x16, 16-bit inputs, f32 accumulate ----
+template <typename Tag> __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma32<bf16_tag>(s16x8 a, s16x8 b, f32x16 c) {
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf8*>(&a), *reinterpret_cast<bf8*>(&b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma32<f16_tag>(s16x8 a, s16x8 b, f32x16 c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8*>(&a), *reinterpret_cast<h8*>(&b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_half_swap(float x) {  // value held by lane ^ 32
+    return __shfl_xor(x, 32, 64);
+}
+
+// XCD-aware block remap: blocks that share blockIdx % 8 share an XCD (and its L2) under the
+// observed round-robin placement (speed only, never correctness).  Returns the logical id such that
+// consecutive logical ids [c*per, (c+1)*per) run on one XCD.  Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace fa

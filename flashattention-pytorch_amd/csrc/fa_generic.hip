@@ -1,0 +1,425 @@
+// Exact-f32 FlashAttention forward / backward for gfx950 (any dtype in, f32 math, head_dim <= 256).
+//
+// This is the path taken for float32 tensors (the reference's parity bar there is 1e-4,
+// tests/utils.py:36, which rules out 16-bit MFMA operands) and for head dims the 16-bit MFMA
+// kernels do not cover (the reference tests d = 32, 40, 48: tests/test_correctness_fa2.py:40,92).
+// All tile GEMMs run on the f32-input matrix instruction v_mfma_f32_16x16x4_f32, whose result is
+// bit-for-bit an f32 fma chain, so the numerics are those of an f32 CPU implementation.
+//
+// Replaces the host tile loops of csrc/fa{1,2,3}/fa?_fwd.cu:56-103 and fa?_bwd.cu:59-110
+// (same math: online softmax over K tiles; backward recomputes P from lse).
+//
+// Layouts (16x16x4 f32 MFMA, lane l): A[row = l&15][k = l>>4], B[k = l>>4][col = l&15],
+// C/D: col = l&15, row = 4*(l>>4) + reg.
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// copy `rows` x d elements (row-major, stride d) starting at row r0 of a (n, d) matrix into an
+// f32 LDS tile with leading dimension LD, zero-filling rows >= n and columns in [d, DP)
+template <typename T, int DP, int LD, int NTHREADS>
+__device__ __forceinline__ void load_tile_f32(float* __restrict__ dst, const T* __restrict__ src, int r0, int rows,
+                                              int n, int d) {
+    for (int idx = threadIdx.x; idx < rows * DP; idx += NTHREADS) {
+        const int r = idx / DP, c = idx - r * DP;
+        float x = 0.f;
+        if (r0 + r < n && c < d) x = to_f32<T>(src[(size_t)(r0 + r) * d + c]);
+        dst[r * LD + c] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: one workgroup = NW waves = 16*NW query rows of one (b,h); key tiles of 32
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DP, int NW>
+__global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ v, T* __restrict__ o,
+                                                          float* __restrict__ lse, int n, int d, int causal,
+                                                          float scale) {
+    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                 // [BM][LD]
+    float* Ks = Qs + BM * LD;         // [BN][LD]
+    float* Vs = Ks + BN * LD;         // [BN][LD]
+    float* Ps = Vs + BN * LD;         // [NW][16][PLD]
+
+    const int ntile = (n + BM - 1) / BM;
+    const int bh = blockIdx.x / ntile;
+    const int q0 = (blockIdx.x - bh * ntile) * BM;
+    const size_t base = (size_t)bh * n * d;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    load_tile_f32<T, DP, LD, NTH>(Qs, q + base, q0, BM, n, d);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m[i] = -INFINITY; l[i] = 0.f; }
+
+    const int kend = causal ? min(n, q0 + BM) : n;  // keys >= kend are masked for every row of the tile
+    float* Pw = Ps + w * 16 * PLD;
+
+    for (int k0 = 0; k0 < kend; k0 += BN) {
+        __syncthreads();
+        load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BN, n, d);
+        load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BN, n, d);
+        __syncthreads();
+
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int s = 0; s < DP / 4; ++s) {
+            const float a = Qs[(w * 16 + lr) * LD + 4 * s + lq];
+            s0 = MFMA_F32(a, Ks[lr * LD + 4 * s + lq], s0);
+            s1 = MFMA_F32(a, Ks[(16 + lr) * LD + 4 * s + lq], s1);
+        }
+        const int key0 = k0 + lr, key1 = k0 + 16 + lr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = q0 + w * 16 + lq * 4 + i;
+            float x0 = s0[i] * scale, x1 = s1[i] * scale;
+            if (key0 >= n || (causal && key0 > row)) x0 = -INFINITY;
+            if (key1 >= n || (causal && key1 > row)) x1 = -INFINITY;
+            float mx = fmaxf(x0, x1);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+            const float mn = fmaxf(m[i], mx);
+            const float msafe = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = expf(m[i] - msafe);
+            const float p0 = expf(x0 - msafe), p1 = expf(x1 - msafe);
+            float rs = p0 + p1;
+            rs += __shfl_xor(rs, 1, 64);
+            rs += __shfl_xor(rs, 2, 64);
+            rs += __shfl_xor(rs, 4, 64);
+            rs += __shfl_xor(rs, 8, 64);
+            l[i] = l[i] * alpha + rs;
+            m[i] = mn;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t][i] *= alpha;
+            Pw[(lq * 4 + i) * PLD + lr] = p0;
+            Pw[(lq * 4 + i) * PLD + 16 + lr] = p1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BN / 4; ++s) {
+            const float a = Pw[lr * PLD + 4 * s + lq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Vs[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = q0 + w * 16 + lq * 4 + i;
+        if (row < n) {
+            const float inv = 1.f / l[i];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 16 * t + lr;
+                if (c < d) o[base + (size_t)row * d + c] = from_f32<T>(acc[t][i] * inv);
+            }
+            if (lr == 0) lse[(size_t)bh * n + row] = m[i] + logf(l[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pre-pass: delta[bh][row] = sum_d dO*O   (csrc/fa2/fa2_bwd.cu:57)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                    float* __restrict__ delta, long long rows, int d) {
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    float s = 0.f;
+    if (row < rows) {
+        const T* po = o + row * d;
+        const T* pd = dout + row * d;
+        for (int c = sub; c < d; c += 16) s += to_f32<T>(po[c]) * to_f32<T>(pd[c]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (row < rows && sub == 0) delta[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV: one workgroup = NW waves = 16*NW keys (resident in LDS); loops over 32-row Q tiles
+// S^T[key][q] and dP^T[key][q] are computed with the key on the MFMA row so that dK/dV accumulate
+// per wave without any cross-workgroup sum.   (csrc/fa2/fa2_bwd.cu:70-109)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DP, int NW>
+__global__ __launch_bounds__(NW * 64) void bwd_dkdv_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ v, const T* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, T* __restrict__ dk,
+                                                               T* __restrict__ dv, int n, int d, int causal,
+                                                               float scale) {
+    constexpr int LD = DP + 4, BK = 16 * NW, BQ = 32, NT = DP / 16, PLD = BQ + 4, NTH = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                   // [BK][LD]
+    float* Vs = Ks + BK * LD;           // [BK][LD]
+    float* Qs = Vs + BK * LD;           // [BQ][LD]
+    float* Os = Qs + BQ * LD;           // [BQ][LD]  (dO)
+    float* Pt = Os + BQ * LD;           // [NW][16][PLD]   P^T
+    float* St = Pt + NW * 16 * PLD;     // [NW][16][PLD]   dS^T
+    float* Ls = St + NW * 16 * PLD;     // [BQ] lse, then [BQ] delta
+
+    const int ntile = (n + BK - 1) / BK;
+    const int bh = blockIdx.x / ntile;
+    const int k0 = (blockIdx.x - bh * ntile) * BK;
+    const size_t base = (size_t)bh * n * d;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BK, n, d);
+    load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BK, n, d);
+
+    f32x4 dka[NT], dva[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { dka[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float* Pw = Pt + w * 16 * PLD;
+    float* Sw = St + w * 16 * PLD;
+
+    const int qstart = causal ? (k0 / BQ) * BQ : 0;  // rows < k0 see none of this tile's keys
+    for (int r0 = qstart; r0 < n; r0 += BQ) {
+        __syncthreads();
+        load_tile_f32<T, DP, LD, NTH>(Qs, q + base, r0, BQ, n, d);
+        load_tile_f32<T, DP, LD, NTH>(Os, dout + base, r0, BQ, n, d);
+        if (threadIdx.x < BQ) {
+            const int r = r0 + threadIdx.x;
+            Ls[threadIdx.x] = r < n ? lse[(size_t)bh * n + r] : 0.f;
+            Ls[BQ + threadIdx.x] = r < n ? delta[(size_t)bh * n + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int s = 0; s < DP / 4; ++s) {
+                st = MFMA_F32(Ks[(w * 16 + lr) * LD + 4 * s + lq], Qs[(qb * 16 + lr) * LD + 4 * s + lq], st);
+                dpt = MFMA_F32(Vs[(w * 16 + lr) * LD + 4 * s + lq], Os[(qb * 16 + lr) * LD + 4 * s + lq], dpt);
+            }
+            const int row = r0 + qb * 16 + lr;  // query index (MFMA column)
+            const float lq_ = Ls[qb * 16 + lr], dl_ = Ls[BQ + qb * 16 + lr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = k0 + w * 16 + lq * 4 + i;
+                const bool ok = row < n && key < n && !(causal && key > row);
+                const float p = ok ? expf(st[i] * scale - lq_) : 0.f;
+                Pw[(lq * 4 + i) * PLD + qb * 16 + lr] = p;
+                Sw[(lq * 4 + i) * PLD + qb * 16 + lr] = p * (dpt[i] - dl_);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BQ / 4; ++s) {
+            const float ap = Pw[lr * PLD + 4 * s + lq];
+            const float as = Sw[lr * PLD + 4 * s + lq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                dva[t] = MFMA_F32(ap, Os[(4 * s + lq) * LD + 16 * t + lr], dva[t]);
+                dka[t] = MFMA_F32(as, Qs[(4 * s + lq) * LD + 16 * t + lr], dka[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = k0 + w * 16 + lq * 4 + i;
+        if (key < n) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 16 * t + lr;
+                if (c < d) {
+                    dk[base + (size_t)key * d + c] = from_f32<T>(dka[t][i] * scale);
+                    dv[base + (size_t)key * d + c] = from_f32<T>(dva[t][i]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: one workgroup = NW waves = 16*NW query rows; loops over 32-key tiles (deterministic,
+// no atomics: S and dP are recomputed a second time here)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DP, int NW>
+__global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                             const T* __restrict__ v, const T* __restrict__ dout,
+                                                             const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dq,
+                                                             int n, int d, int causal, float scale) {
+    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                // [BM][LD]
+    float* Os = Qs + BM * LD;        // [BM][LD]  (dO)
+    float* Ks = Os + BM * LD;        // [BN][LD]
+    float* Vs = Ks + BN * LD;        // [BN][LD]
+    float* Ss = Vs + BN * LD;        // [NW][16][PLD]  dS
+
+    const int ntile = (n + BM - 1) / BM;
+    const int bh = blockIdx.x / ntile;
+    const int q0 = (blockIdx.x - bh * ntile) * BM;
+    const size_t base = (size_t)bh * n * d;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    load_tile_f32<T, DP, LD, NTH>(Qs, q + base, q0, BM, n, d);
+    load_tile_f32<T, DP, LD, NTH>(Os, dout + base, q0, BM, n, d);
+
+    float lrow[4], drow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = q0 + w * 16 + lq * 4 + i;
+        lrow[i] = row < n ? lse[(size_t)bh * n + row] : 0.f;
+        drow[i] = row < n ? delta[(size_t)bh * n + row] : 0.f;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* Sw = Ss + w * 16 * PLD;
+
+    const int kend = causal ? min(n, q0 + BM) : n;
+    for (int k0 = 0; k0 < kend; k0 += BN) {
+        __syncthreads();
+        load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BN, n, d);
+        load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BN, n, d);
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int ks = 0; ks < DP / 4; ++ks) {
+                s = MFMA_F32(Qs[(w * 16 + lr) * LD + 4 * ks + lq], Ks[(nb * 16 + lr) * LD + 4 * ks + lq], s);
+                dp = MFMA_F32(Os[(w * 16 + lr) * LD + 4 * ks + lq], Vs[(nb * 16 + lr) * LD + 4 * ks + lq], dp);
+            }
+            const int key = k0 + nb * 16 + lr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = q0 + w * 16 + lq * 4 + i;
+                const bool ok = row < n && key < n && !(causal && key > row);
+                const float p = ok ? expf(s[i] * scale - lrow[i]) : 0.f;
+                Sw[(lq * 4 + i) * PLD + nb * 16 + lr] = p * (dp[i] - drow[i]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BN / 4; ++s) {
+            const float a = Sw[lr * PLD + 4 * s + lq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Ks[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = q0 + w * 16 + lq * 4 + i;
+        if (row < n) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 16 * t + lr;
+                if (c < d) dq[base + (size_t)row * d + c] = from_f32<T>(acc[t][i] * scale);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t set_smem(K kern, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T, int DP, int NW>
+static hipError_t launch_fwd_f32_t(const FwdArgs& a, hipStream_t st) {
+    constexpr int LD = DP + 4;
+    const size_t smem = sizeof(float) * ((16 * NW + 64) * LD + NW * 16 * 36);
+    auto kern = fwd_f32_kernel<T, DP, NW>;
+    hipError_t e = set_smem(kern, smem);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+    ProfScope ps(K_FWD_F32, st);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v, (T*)a.o, a.lse,
+                       (int)a.n, (int)a.d, a.causal, a.scale);
+    return hipGetLastError();
+}
+
+template <typename T, int DP, int NW>
+static hipError_t launch_bwd_f32_t(const BwdArgs& a, hipStream_t st) {
+    constexpr int LD = DP + 4;
+    float* delta = reinterpret_cast<float*>(a.workspace);
+    const long long rows = (long long)a.bh * a.n;
+    {
+        ProfScope ps(K_BWD_DELTA, st);
+        hipLaunchKernelGGL(delta_kernel<T>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, (const T*)a.o,
+                           (const T*)a.dout, delta, rows, (int)a.d);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    {
+        const size_t smem = sizeof(float) * ((2 * 16 * NW + 64) * LD + 2 * NW * 16 * 36 + 64);
+        auto kern = bwd_dkdv_f32_kernel<T, DP, NW>;
+        e = set_smem(kern, smem);
+        if (e != hipSuccess) return e;
+        dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+        ProfScope ps(K_BWD_DKDV_F32, st);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
+                           (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dk, (T*)a.dv, (int)a.n, (int)a.d,
+                           a.causal, a.scale);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        const size_t smem = sizeof(float) * ((2 * 16 * NW + 64) * LD + NW * 16 * 36);
+        auto kern = bwd_dq_f32_kernel<T, DP, NW>;
+        e = set_smem(kern, smem);
+        if (e != hipSuccess) return e;
+        dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+        ProfScope ps(K_BWD_DQ_F32, st);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
+                           (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dq, (int)a.n, (int)a.d, a.causal,
+                           a.scale);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+template <typename T>
+static hipError_t fwd_by_d(const FwdArgs& a, hipStream_t st) {
+    if (a.d <= 64) return launch_fwd_f32_t<T, 64, 4>(a, st);
+    if (a.d <= 128) return launch_fwd_f32_t<T, 128, 4>(a, st);
+    return launch_fwd_f32_t<T, 256, 4>(a, st);
+}
+template <typename T>
+static hipError_t bwd_by_d(const BwdArgs& a, hipStream_t st) {
+    if (a.d <= 64) return launch_bwd_f32_t<T, 64, 4>(a, st);
+    if (a.d <= 128) return launch_bwd_f32_t<T, 128, 4>(a, st);
+    return launch_bwd_f32_t<T, 256, 2>(a, st);
+}
+
+hipError_t launch_fwd_generic(const FwdArgs& a, hipStream_t st) {
+    switch (a.dtype) {
+        case 0: return fwd_by_d<float>(a, st);
+        case 1: return fwd_by_d<__half>(a, st);
+        default: return fwd_by_d<__hip_bfloat16>(a, st);
+    }
+}
+hipError_t launch_bwd_generic(const BwdArgs& a, hipStream_t st) {
+    switch (a.dtype) {
+        case 0: return bwd_by_d<float>(a, st);
+        case 1: return bwd_by_d<__half>(a, st);
+        default: return bwd_by_d<__hip_bfloat16>(a, st);
+    }
+}
+size_t bwd_generic_workspace_bytes(int64_t bh, int64_t n) { return sizeof(float) * (size_t)bh * (size_t)n; }
+
+}  // namespace fa

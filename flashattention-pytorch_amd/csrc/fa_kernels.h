@@ -1,0 +1,60 @@
+// Internal launcher interface between the C-ABI layer (fa_capi.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fa {
+
+struct FwdArgs {
+    const void *q, *k, *v;
+    void* o;
+    float* lse;
+    int64_t bh, n, d;
+    int dtype;  // FA_DTYPE_*
+    int causal;
+    float scale;
+};
+
+struct BwdArgs {
+    const void *q, *k, *v, *o, *dout;
+    const float* lse;
+    void *dq, *dk, *dv;
+    int64_t bh, n, d;
+    int dtype;
+    int causal;
+    float scale;
+    void* workspace;
+    size_t workspace_bytes;
+};
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+// roofline figure; off by default, costs nothing when off).
+enum KernelId { K_FWD_F32 = 0, K_BWD_DELTA, K_BWD_DKDV_F32, K_BWD_DQ_F32, K_FWD_MFMA, K_BWD_MFMA, K_BWD_DQ_CVT,
+                K_FP8_QUANT, K_FWD_FP8, K_COUNT };
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+struct ProfScope {
+    int id; hipStream_t st;
+    ProfScope(int i, hipStream_t s) : id(i), st(s) { prof_begin(id, st); }
+    ~ProfScope() { prof_end(id, st); }
+};
+
+// exact-f32 kernels (fa_generic.hip): any dtype, d <= 256
+hipError_t launch_fwd_generic(const FwdArgs& a, hipStream_t st);
+hipError_t launch_bwd_generic(const BwdArgs& a, hipStream_t st);
+size_t bwd_generic_workspace_bytes(int64_t bh, int64_t n);
+
+// 16-bit MFMA kernels (fa_fwd_mfma.hip / fa_bwd_mfma.hip): f16/bf16, d in {64, 128}
+bool fwd_mfma_supported(int dtype, int64_t d);
+hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st);
+bool bwd_mfma_supported(int dtype, int64_t d);
+hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
+size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d);
+
+// FA3-style fp8 forward (fa_fwd_fp8.hip): Q/K quantised to e4m3 per 64-row block, S on the fp8 MFMA
+bool fwd_fp8_supported(int dtype, int64_t d);
+hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st);
+size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
+
+}  // namespace fa

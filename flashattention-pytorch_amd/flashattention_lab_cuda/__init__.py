@@ -1,0 +1,196 @@
+"""`flashattention_lab_cuda` — the extension module the reference's wrappers look up by name
+(`/root/reference/src/fa2/cuda/impl.py:10`), re-created as a thin ctypes shim over the C-ABI
+library `libfa_mi355x.so` (declared in `include/fa_mi355x.h`, built from `csrc/`).
+
+Exports exactly the six names of `/root/reference/csrc/common/torch.extension.cpp:73-83` with the
+same positional signatures:
+
+    fa1_forward / forward (q, k, v, causal, softmax_scale, br, bc)              -> (o, lse)
+    fa1_backward / backward (q, k, v, o, do_, lse, causal, softmax_scale, br, bc) -> (dq, dk, dv)
+    fa3_forward (q, k, v, causal, softmax_scale, br, bc, stages, fp8)           -> (o, lse)
+    fa3_backward(q, k, v, o, do_, lse, causal, softmax_scale, br, bc, stages, fp8) -> (dq, dk, dv)
+
+As in the reference (`csrc/fa2/fa2_fwd.cu:38-54`, `fa2_bwd.cu:112-115`): inputs are (BH, N, d) device
+tensors, `o` and the gradients come back in the input dtype, `lse` is float32, nothing is recorded by
+autograd, inputs are never modified, and shape errors raise RuntimeError.  PyTorch is used only to
+allocate the outputs / workspace and to name the current HIP stream; all compute is in the HIP library.
+There is NO CPU fallback: a missing library or a non-device tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfa_mi355x.so")
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+EXPORTED_C_SYMBOLS = (
+    "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
+    "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa_last_error", "fa_version",
+    "fa_set_kernel_mode", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
+)
+
+
+def _load_library() -> ctypes.CDLL:
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} not found: build it with `make -C flashattention-pytorch_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`)"
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, i64, ci, dbl, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    fwd = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, dbl, i64, i64, vp]
+    bwd = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, dbl, i64, i64, vp, sz, vp]
+    for name in ("fa1_forward", "fa2_forward"):
+        getattr(lib, name).argtypes = fwd
+        getattr(lib, name).restype = ci
+    for name in ("fa1_backward", "fa2_backward"):
+        getattr(lib, name).argtypes = bwd
+        getattr(lib, name).restype = ci
+    lib.fa3_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, dbl, i64, i64, i64, ci, vp, sz, vp]
+    lib.fa3_forward.restype = ci
+    lib.fa3_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, dbl, i64, i64, i64, ci, vp, sz, vp]
+    lib.fa3_backward.restype = ci
+    lib.fa_backward_workspace_bytes.argtypes = [i64, i64, i64, ci]
+    lib.fa_backward_workspace_bytes.restype = sz
+    lib.fa3_forward_workspace_bytes.argtypes = [i64, i64, i64, ci, ci]
+    lib.fa3_forward_workspace_bytes.restype = sz
+    lib.fa_last_error.restype = ctypes.c_char_p
+    lib.fa_version.restype = ctypes.c_char_p
+    lib.fa_set_kernel_mode.argtypes = [ci]
+    lib.fa_set_kernel_mode.restype = ci
+    lib.fa_device_is_gfx950.argtypes = [ci]
+    lib.fa_device_is_gfx950.restype = ci
+    lib.fa_profile_enable.argtypes = [ci]
+    lib.fa_profile_enable.restype = ci
+    lib.fa_profile_report.argtypes = [ctypes.c_char_p, sz]
+    lib.fa_profile_report.restype = ci
+    return lib
+
+
+_lib = _load_library()
+LIBRARY_PATH = _LIB_PATH
+
+
+def version() -> str:
+    return _lib.fa_version().decode()
+
+
+def set_kernel_mode(mode: int) -> int:
+    """0 = auto (16-bit MFMA kernels where they apply), 1 = force the exact-f32 kernels. Returns the old mode."""
+    return _lib.fa_set_kernel_mode(int(mode))
+
+
+def profile_enable(on: bool) -> None:
+    """Start (and clear) or stop per-kernel HIP-event timing inside the library."""
+    _lib.fa_profile_enable(int(bool(on)))
+
+
+def profile_report() -> dict:
+    """{kernel_name: (launches, total_ms)} for the launches since profile_enable(True); waits for the events."""
+    buf = ctypes.create_string_buffer(4096)
+    n = _lib.fa_profile_report(buf, 4096)
+    if n < 0:
+        raise RuntimeError(_lib.fa_last_error().decode())
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(_lib.fa_last_error().decode())
+
+
+def _check_inputs(who, *tensors):
+    t0 = tensors[0]
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"{who}: tensors must be on the GPU (HIP device); there is no CPU path")
+    if t0.dim() != 3:
+        raise RuntimeError(f"{who}: q must be 3-D (BH, N, d), got {tuple(t0.shape)}")  # fa2_fwd.cu:40
+    for t in tensors:
+        if t.shape != t0.shape or t.dtype != t0.dtype or t.device != t0.device:
+            raise RuntimeError(f"{who}: q, k, v (o, do) must share shape, dtype and device")  # fa2_fwd.cu:41-45
+    if t0.dtype not in _DTYPE_CODE:
+        raise RuntimeError(f"{who}: unsupported dtype {t0.dtype}")
+    return _DTYPE_CODE[t0.dtype]
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _forward(cfn, who, q, k, v, causal, softmax_scale, br, bc, extra=None):
+    code = _check_inputs(who, q, k, v)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    bh, n, d = q.shape
+    with torch.cuda.device(q.device):
+        o = torch.empty_like(q)
+        lse = torch.empty((bh, n), dtype=torch.float32, device=q.device)
+        args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), bh, n, d, code,
+                int(bool(causal)), float(softmax_scale), int(br), int(bc)]
+        ws = None
+        if extra is not None:
+            stages, fp8 = extra
+            nbytes = _lib.fa3_forward_workspace_bytes(bh, n, d, code, int(bool(fp8)))
+            ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=q.device)
+            args += [int(stages), int(bool(fp8)), ws.data_ptr(), int(nbytes)]
+        args.append(_stream_ptr(q.device))
+        _check(cfn(*args))
+    return o, lse
+
+
+def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, extra=None):
+    code = _check_inputs(who, q, k, v, o, do_)
+    q, k, v, o, do_ = (t.contiguous() for t in (q, k, v, o, do_))
+    bh, n, d = q.shape
+    if lse.shape != (bh, n) or lse.dtype != torch.float32 or not lse.is_cuda:
+        raise RuntimeError(f"{who}: lse must be a float32 device tensor of shape (BH, N)")
+    lse = lse.contiguous()
+    with torch.cuda.device(q.device):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
+                dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, n, d, code, int(bool(causal)),
+                float(softmax_scale), int(br), int(bc)]
+        if extra is not None:
+            stages, fp8 = extra
+            args += [int(stages), int(bool(fp8))]
+        args += [ws.data_ptr(), nbytes, _stream_ptr(q.device)]
+        _check(cfn(*args))
+    return dq, dk, dv
+
+
+# ---- the six names of csrc/common/torch.extension.cpp:73-83 ----
+
+def fa1_forward(q, k, v, causal, softmax_scale, br, bc):
+    return _forward(_lib.fa1_forward, "fa1_forward", q, k, v, causal, softmax_scale, br, bc)
+
+
+def fa1_backward(q, k, v, o, do_, lse, causal, softmax_scale, br, bc):
+    return _backward(_lib.fa1_backward, "fa1_backward", q, k, v, o, do_, lse, causal, softmax_scale, br, bc)
+
+
+def forward(q, k, v, causal, softmax_scale, br, bc):
+    return _forward(_lib.fa2_forward, "forward", q, k, v, causal, softmax_scale, br, bc)
+
+
+def backward(q, k, v, o, do_, lse, causal, softmax_scale, br, bc):
+    return _backward(_lib.fa2_backward, "backward", q, k, v, o, do_, lse, causal, softmax_scale, br, bc)
+
+
+def fa3_forward(q, k, v, causal, softmax_scale, br, bc, stages, fp8):
+    return _forward(_lib.fa3_forward, "fa3_forward", q, k, v, causal, softmax_scale, br, bc, extra=(stages, fp8))
+
+
+def fa3_backward(q, k, v, o, do_, lse, causal, softmax_scale, br, bc, stages, fp8):
+    return _backward(_lib.fa3_backward, "fa3_backward", q, k, v, o, do_, lse, causal, softmax_scale, br, bc,
+                     extra=(stages, fp8))

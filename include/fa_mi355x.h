@@ -1,0 +1,111 @@
+/*
+ * fa_mi355x.h — C ABI of the MI355X (gfx950) FlashAttention forward/backward library.
+ *
+ * This is the drop-in boundary for the hot path of PeTeRr0/FlashAttention-pytorch.
+ * The six `fa*_forward/backward` entry points below are what the reference's Python
+ * wrappers call on its native extension module (reference file:line, relative to the
+ * reference tree):
+ *
+ *   csrc/common/torch.extension.cpp:74  m.def("fa1_forward",  &fa1_forward)   -> fa1_forward
+ *   csrc/common/torch.extension.cpp:75  m.def("fa1_backward", &fa1_backward)  -> fa1_backward
+ *   csrc/common/torch.extension.cpp:78  m.def("forward",      &fa2_forward)   -> fa2_forward
+ *   csrc/common/torch.extension.cpp:79  m.def("backward",     &fa2_backward)  -> fa2_backward
+ *   csrc/common/torch.extension.cpp:81  m.def("fa3_forward",  &fa3_forward)   -> fa3_forward
+ *   csrc/common/torch.extension.cpp:82  m.def("fa3_backward", &fa3_backward)  -> fa3_backward
+ *
+ * The reference's functions take and return `torch::Tensor`; here every tensor is a
+ * plain device pointer plus sizes, the caller owns all memory (inputs, outputs and the
+ * backward workspace), and work is enqueued on the caller's `hipStream_t` (passed as
+ * `void*`) without synchronising the device.  The Python shim
+ * `flashattention-pytorch_amd/flashattention_lab_cuda/__init__.py` re-creates the
+ * reference's tensor-level signatures on top of these via ctypes.
+ *
+ * Tensor layout (same as the reference, csrc/fa2/fa2_fwd.cu:40-54):
+ *   q, k, v, o, do, dq, dk, dv : contiguous row-major (BH, N, d), element type `dtype`
+ *   lse                        : contiguous (BH, N) float32, natural-log logsumexp
+ * Results do not depend on the tile hints `br`, `bc`, `stages`.
+ *
+ * Every function returns FA_OK (0) or a negative error code; `fa_last_error()` returns a
+ * thread-local message for the last failure.
+ */
+#ifndef FA_MI355X_H
+#define FA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_OK 0
+#define FA_ERR_INVALID_ARGUMENT (-1) /* bad shape / dtype / null pointer (reference: TORCH_CHECK -> RuntimeError) */
+#define FA_ERR_UNSUPPORTED (-2)      /* head_dim > 256, or no gfx950 device */
+#define FA_ERR_WORKSPACE (-3)        /* workspace too small */
+#define FA_ERR_LAUNCH (-4)           /* HIP launch error */
+
+/* element type of q/k/v/o/do/dq/dk/dv */
+#define FA_DTYPE_F32 0
+#define FA_DTYPE_F16 1
+#define FA_DTYPE_BF16 2
+
+/* Which implementation the dispatcher picks (fa_set_kernel_mode): AUTO = MFMA bf16/f16 kernels
+ * when dtype is 16-bit and d is 64 or 128, exact-f32 MFMA kernels otherwise. */
+#define FA_MODE_AUTO 0
+#define FA_MODE_F32_GENERIC 1
+
+/* --- FlashAttention-1 names (replaces csrc/fa1/fa1_fwd.cu:30, csrc/fa1/fa1_bwd.cu:30) --- */
+int fa1_forward(const void* q, const void* k, const void* v, void* o, float* lse,
+                int64_t bh, int64_t n, int64_t d, int dtype,
+                int causal, double softmax_scale, int64_t br, int64_t bc, void* stream);
+
+int fa1_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv,
+                 int64_t bh, int64_t n, int64_t d, int dtype,
+                 int causal, double softmax_scale, int64_t br, int64_t bc,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- FlashAttention-2 (Python names `forward` / `backward`; replaces csrc/fa2/fa2_fwd.cu:30, fa2_bwd.cu:30) --- */
+int fa2_forward(const void* q, const void* k, const void* v, void* o, float* lse,
+                int64_t bh, int64_t n, int64_t d, int dtype,
+                int causal, double softmax_scale, int64_t br, int64_t bc, void* stream);
+
+int fa2_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv,
+                 int64_t bh, int64_t n, int64_t d, int dtype,
+                 int causal, double softmax_scale, int64_t br, int64_t bc,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- FlashAttention-3 (replaces csrc/fa3/fa3_fwd.cu:172, csrc/fa3/fa3_bwd.cu:104).
+ * fp8 != 0: Q and K are quantised to OCP e4m3 with one scale per (bh, 64-row block) and QK^T runs
+ * on the fp8 MFMA; V, P and all accumulation stay 16/32-bit.  Needs dtype f16/bf16 and d in {64,128};
+ * the forward then also needs a workspace (fa3_forward_workspace_bytes). The backward differentiates
+ * the un-quantised function (straight-through), as the reference's tests require (tolerance 1e-1). */
+int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse,
+                int64_t bh, int64_t n, int64_t d, int dtype,
+                int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+int fa3_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                 void* dq, void* dk, void* dv,
+                 int64_t bh, int64_t n, int64_t d, int dtype,
+                 int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */
+size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype);
+size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
+const char* fa_last_error(void);
+const char* fa_version(void);
+int fa_set_kernel_mode(int mode);      /* FA_MODE_*; returns the previous mode */
+int fa_device_is_gfx950(int device);   /* 1 if `device` reports gcnArchName gfx950, 0 otherwise, <0 on HIP error */
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figure).
+ * fa_profile_enable(1) starts collecting (and clears old records), fa_profile_report waits for the events and
+ * writes one "kernel_name launches total_ms" line per kernel; returns bytes written or a negative code. */
+int fa_profile_enable(int on);
+int fa_profile_report(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_MI355X_H */
