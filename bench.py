@@ -45,6 +45,8 @@ def cpu_baseline(n, d, dtype, causal, budget_s):
     from fa2.spec import pick_fa2_spec
 
     spec = pick_fa2_spec(d)
+    # the reference's tile loops issue many small matmuls: beyond ~16 threads they get slower, not faster
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     g = torch.Generator().manual_seed(0)
     units, elapsed = 0, 0.0
     t_all = time.perf_counter()

@@ -1,0 +1,409 @@
+// FlashAttention backward for gfx950, 16-bit inputs (bf16 / f16), head_dim 64 or 128.
+//
+// Replaces the host tile loop of csrc/fa2/fa2_bwd.cu:57-110 (and fa1/fa3 siblings):
+//   delta = rowsum(dO * O);  per (K tile, Q tile): P = exp(S - lse), dV += P^T dO, dP = dO V^T,
+//   dS = P * (dP - delta), dQ += dS K * scale, dK += dS^T Q * scale        (fp32 accumulation).
+//
+// Three launches:
+//   1. bwd_prep_kernel   : nlse = -lse / scale, ndelta = -rowsum(dO*O)   (row constants, fp32 workspace)
+//   2. bwd_mfma_kernel   : one workgroup = 4 waves = 256 keys of one (b,h); every wave keeps dK^T and dV^T of
+//                          its 64 keys in 256 accumulator registers (one wave per SIMD, 512-register budget)
+//                          while the workgroup sweeps 32-row query slices.  dQ partial tiles are summed into an
+//                          fp32 scratch with global float atomics (one 32x32 tile per wave per slice).
+//   3. dq_convert_kernel : dq = (dtype)(scale * dq_scratch)
+//
+// MFMA orientation ("key on the lane"): S[q][key] and dP[q][key] are computed with the key as the accumulator
+// column (lane & 31), so the P and dS accumulators are directly the B operands of dV^T += dO^T P and
+// dK^T += Q^T dS (an accumulator tile as the next MFMA's operand); only dS crosses LDS, once, transposed,
+// for dQ += dS K.  The row constants -lse/scale and -delta are loaded as the INITIAL accumulators of the S and
+// dP chains, so P = exp2(c * S') and dS = P * dP' need no subtraction.
+//
+// LDS images (all 16-bit, XOR-swizzled 16-byte chunks, see TileSwz in fa_fwd_mfma.hip / below):
+//   Ks  [256 keys][D]   read by rows (B operand of S) and by columns (ds_read_b64_tr_b16, B operand of dQ)
+//   Qs  [2][32][D]      read by rows (A operand of S) and by columns (A operand of dK^T)
+//   dOs [2][32][D]      read by rows (A operand of dP) and by columns (A operand of dV^T)
+//   dSs [256 keys][32 q]  written 8 B per lane from the accumulators, read by columns (A operand of dQ)
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <int D> struct TileSwzB;
+template <> struct TileSwzB<128> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+};
+template <> struct TileSwzB<64> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
+};
+// dS^T image: 64-byte rows (32 queries), 8-byte slots
+__device__ __forceinline__ int ds_off(int key, int slot) { return 64 * key + 8 * (slot ^ ((key >> 1) & 7)); }
+
+typedef short lds_s16x4b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4b __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// ------------------------------------------------------------------------------------------------
+template <typename Tag>
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
+                                                       const float* __restrict__ lse, float* __restrict__ nlse,
+                                                       float* __restrict__ ndelta, long long rows, int d,
+                                                       float inv_scale) {
+    // 16 lanes per row, 8 elements (16 B) per lane per step
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    float s = 0.f;
+    if (row < rows) {
+        for (int c = sub * 8; c < d; c += 128) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(o + row * d + c);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(dout + row * d + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s += unpack_lo<Tag>(a[j]) * unpack_lo<Tag>(b[j]) + unpack_hi<Tag>(a[j]) * unpack_hi<Tag>(b[j]);
+        }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (row < rows && sub == 0) {
+        ndelta[row] = -s;
+        nlse[row] = -lse[row] * inv_scale;
+    }
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void dq_convert_kernel(const float* __restrict__ acc, uint16_t* __restrict__ dq,
+                                                         long long n8, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(acc + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(acc + i * 8 + 4);
+    u32x4 r;
+    r[0] = pack2_rn<Tag>(a[0] * scale, a[1] * scale);
+    r[1] = pack2_rn<Tag>(a[2] * scale, a[3] * scale);
+    r[2] = pack2_rn<Tag>(b[0] * scale, b[1] * scale);
+    r[3] = pack2_rn<Tag>(b[2] * scale, b[3] * scale);
+    *reinterpret_cast<u32x4*>(dq + i * 8) = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                          const uint16_t* __restrict__ v,
+                                                          const uint16_t* __restrict__ dout,
+                                                          const float* __restrict__ nlse,
+                                                          const float* __restrict__ ndelta, float* __restrict__ dq_acc,
+                                                          uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int n,
+                                                          int nkt, float c_log2, float scale) {
+    constexpr int BK = 256, BQ = 32, NKS = D / 16, NDB = D / 32, CPR = D / 8;
+    constexpr int K_BYTES = BK * D * 2, Q_BYTES = BQ * D * 2, DS_BYTES = BK * BQ * 2;
+    constexpr int LPT = (BQ * CPR) / 256;          // 16-B chunks per thread per tensor per slice
+    constexpr int KSPLIT = 4 / NDB;                // waves sharing one dQ tile (1 for D=128, 2 for D=64)
+    constexpr int KSTEPS = (BK / 16) / KSPLIT;     // 16-key steps per wave in the dQ product
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Qs = Ks + K_BYTES;              // [2][Q_BYTES]
+    char* Os = Qs + 2 * Q_BYTES;          // [2][Q_BYTES]   (dO)
+    char* Ss = Os + 2 * Q_BYTES;          // dS^T
+    float* Ls = reinterpret_cast<float*>(Ss + DS_BYTES);  // [2][2][32]: (-lse/scale, -delta) per buffer
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nkt;
+    const int kt = L - bh * nkt;          // key tile; under the causal mask tile 0 is the heaviest and goes first
+    const int key0 = kt * BK;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const size_t base = (size_t)bh * n * D;
+    const size_t rbase = (size_t)bh * n;
+
+    // ---- K tile -> LDS (zero rows past n)
+    for (int c = tid; c < BK * CPR; c += 256) {
+        const int row = c / CPR, ch = c - row * CPR;
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (key0 + row < n) t = *reinterpret_cast<const u32x4*>(k + base + (size_t)(key0 + row) * D + 8 * ch);
+        *reinterpret_cast<u32x4*>(Ks + TileSwzB<D>::off(row, ch)) = t;
+    }
+    // ---- V fragments (B operand of dP = dO V^T): lane holds V[key][16 ks + 8 h .. +7] for its two key blocks
+    s16x8 vf[2][NKS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = key0 + 64 * w + 32 * kb + r;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 t = {0u, 0u, 0u, 0u};
+            if (key < n) t = *reinterpret_cast<const u32x4*>(v + base + (size_t)key * D + 16 * ks + 8 * h);
+            vf[kb][ks] = *reinterpret_cast<s16x8*>(&t);
+        }
+    }
+
+    // ---- Q / dO slice staging
+    int st_row[LPT], st_ch[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int c = tid + 256 * i;
+        st_row[i] = c / CPR;
+        st_ch[i] = c - st_row[i] * CPR;
+    }
+    u32x4 qreg[LPT], oreg[LPT];
+    float lreg = 0.f;
+    auto stage_load = [&](int qs) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = qs + st_row[i];
+            qreg[i] = u32x4{0u, 0u, 0u, 0u};
+            oreg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (row < n) {
+                const size_t g = base + (size_t)row * D + 8 * st_ch[i];
+                qreg[i] = *reinterpret_cast<const u32x4*>(q + g);
+                oreg[i] = *reinterpret_cast<const u32x4*>(dout + g);
+            }
+        }
+        if (tid < 64) {
+            const int row = qs + (tid & 31);
+            if (tid < 32) lreg = row < n ? nlse[rbase + row] : -1e30f;
+            else lreg = row < n ? ndelta[rbase + row] : 0.f;
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int off = TileSwzB<D>::off(st_row[i], st_ch[i]);
+            *reinterpret_cast<u32x4*>(Qs + buf * Q_BYTES + off) = qreg[i];
+            *reinterpret_cast<u32x4*>(Os + buf * Q_BYTES + off) = oreg[i];
+        }
+        if (tid < 64) Ls[buf * 64 + tid] = lreg;
+    };
+
+    f32x16 dka[2][NDB], dva[2][NDB];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < NDB; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dka[kb][t][i] = 0.f; dva[kb][t][i] = 0.f; }
+
+    const int qs_first = CAUSAL ? (key0 / BQ) * BQ : 0;   // query slices before the tile's first key see none of it
+    const int nslice = (n - qs_first + BQ - 1) / BQ;
+    stage_load(qs_first);
+    stage_write(0);
+    __syncthreads();
+
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+    const int db_q = w % NDB, kpart = w / NDB;
+
+    for (int it = 0; it < nslice; ++it) {
+        const int qs = qs_first + it * BQ;
+        const int cur = it & 1;
+        if (it + 1 < nslice) stage_load(qs + BQ);
+        const char* Qt = Qs + cur * Q_BYTES;
+        const char* Ot = Os + cur * Q_BYTES;
+        const float* Lt = Ls + cur * 64;
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int kw0 = key0 + 64 * w + 32 * kb;          // first key of this wave's block
+            const int kl = 64 * w + 32 * kb + r;              // this lane's key, local to the tile
+            const bool active = (kw0 < n) && (!CAUSAL || kw0 <= qs + BQ - 1);
+            u32x4 pp[2], sp[2];                               // packed P and dS: k-steps s = 0, 1
+            if (active) {
+                // ---- S' = Q K^T - lse/scale,  dP' = dO V^T - delta   (row constants as initial accumulators)
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(Lt + 8 * g + 4 * h);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(Lt + 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = a[j]; pacc[4 * g + j] = b[j]; }
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const s16x8 qa = *reinterpret_cast<const s16x8*>(Qt + TileSwzB<D>::off(r, 2 * ks + h));
+                    const s16x8 kbf = *reinterpret_cast<const s16x8*>(Ks + TileSwzB<D>::off(64 * w + 32 * kb + r, 2 * ks + h));
+                    mfma32_v<Tag>(qa, kbf, sacc);
+                    const s16x8 oa = *reinterpret_cast<const s16x8*>(Ot + TileSwzB<D>::off(r, 2 * ks + h));
+                    mfma32_v<Tag>(oa, vf[kb][ks], pacc);
+                    if (D > 64 && (ks & 1)) __builtin_amdgcn_sched_barrier(0);   // bound the operand prefetch depth
+                }
+                mfma_result_fence(sacc, pacc);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- P = exp2(c S'), dS = P dP'; mask on diagonal / ragged blocks
+                const bool need_mask = (CAUSAL && (kw0 + 31 > qs)) || (kw0 + 32 > n);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                    if (need_mask) {
+                        const int qrow = qs + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key0 + kl >= n || (CAUSAL && key0 + kl > qrow)) p = 0.f;
+                    }
+                    sacc[i] = p;
+                    pacc[i] = p * pacc[i];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pp[s][j] = pack2<Tag>(sacc[8 * s + 2 * j], sacc[8 * s + 2 * j + 1]);
+                        sp[s][j] = pack2<Tag>(pacc[8 * s + 2 * j], pacc[8 * s + 2 * j + 1]);
+                    }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { pp[s] = u32x4{0u, 0u, 0u, 0u}; sp[s] = u32x4{0u, 0u, 0u, 0u}; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- dS^T -> LDS: lane (key kl) writes the 4 queries 8g + 4h .. +3 of register group g as 8 bytes
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 t;
+                t[0] = sp[g >> 1][2 * (g & 1)];
+                t[1] = sp[g >> 1][2 * (g & 1) + 1];
+                *reinterpret_cast<u32x2*>(Ss + ds_off(kl, 2 * g + h)) = t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // ---- dV^T += dO^T P ,  dK^T += Q^T dS   (A operands: transposed reads of the dO / Q tiles).
+                // Unconditional on purpose: an inactive block (causal, before its diagonal) adds zeros.  Guarding
+                // the accumulate makes hipcc merge the 256 resident accumulators through VGPR copies every slice.
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[s]);
+                    const s16x8 sb = *reinterpret_cast<s16x8*>(&sp[s]);
+                    const int qa = 16 * s + 4 * h + tq;   // rows (queries) of the first 4-row block; second is +8
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const int ch = 4 * db + 2 * g16 + (tp >> 1);
+                        const int o1 = TileSwzB<D>::off(qa, ch) + 8 * (tp & 1);
+                        const int o2 = TileSwzB<D>::off(qa + 8, ch) + 8 * (tp & 1);
+                        const s16x8 doT = cat8(lds_tr16(Ot + o1), lds_tr16(Ot + o2));
+                        dva[kb][db] = mfma32<Tag>(doT, pb, dva[kb][db]);
+                        const s16x8 qT = cat8(lds_tr16(Qt + o1), lds_tr16(Qt + o2));
+                        dka[kb][db] = mfma32<Tag>(qT, sb, dka[kb][db]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // dS^T of all 256 keys is in LDS
+
+        // ---- dQ tile (32 queries x 32 columns db_q) = sum over this wave's share of the 256 keys of dS K
+        {
+            f32x16 dqa;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dqa[i] = 0.f;
+            // keys past the slice's last query are masked (dS = 0): stop there under the causal mask
+            int ksteps = KSTEPS;
+            if (CAUSAL) {
+                const int lim = (qs + BQ - key0 + 15) / 16 - kpart * KSTEPS;   // 16-key steps that can be non-zero
+                ksteps = lim < KSTEPS ? (lim < 0 ? 0 : lim) : KSTEPS;
+            }
+            for (int st = 0; st < ksteps; ++st) {
+                const int kb16 = 16 * (kpart * KSTEPS + st);
+                const int ka = kb16 + 4 * h + tq;
+                const s16x8 a = cat8(lds_tr16(Ss + ds_off(ka, 4 * g16 + tp)), lds_tr16(Ss + ds_off(ka + 8, 4 * g16 + tp)));
+                const int ch = 4 * db_q + 2 * g16 + (tp >> 1);
+                const s16x8 b = cat8(lds_tr16(Ks + TileSwzB<D>::off(ka, ch) + 8 * (tp & 1)),
+                                     lds_tr16(Ks + TileSwzB<D>::off(ka + 8, ch) + 8 * (tp & 1)));
+                mfma32_v<Tag>(a, b, dqa);
+            }
+            mfma_result_fence(dqa);
+            if (ksteps > 0) {
+                float* dst = dq_acc + (rbase + qs) * D + 32 * db_q + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (qs + row < n) atomicAdd(dst + (size_t)row * D, dqa[i]);
+                }
+            }
+        }
+        if (it + 1 < nslice) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = key0 + 64 * w + 32 * kb + r;
+        if (key < n) {
+            uint16_t* dkrow = dk + base + (size_t)key * D;
+            uint16_t* dvrow = dv + base + (size_t)key * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 a, b;
+                    a[0] = pack2_rn<Tag>(dka[kb][db][4 * g + 0] * scale, dka[kb][db][4 * g + 1] * scale);
+                    a[1] = pack2_rn<Tag>(dka[kb][db][4 * g + 2] * scale, dka[kb][db][4 * g + 3] * scale);
+                    b[0] = pack2_rn<Tag>(dva[kb][db][4 * g + 0], dva[kb][db][4 * g + 1]);
+                    b[1] = pack2_rn<Tag>(dva[kb][db][4 * g + 2], dva[kb][db][4 * g + 3]);
+                    *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * h) = a;
+                    *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * h) = b;
+                }
+        }
+    }
+}
+
+bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
+
+// workspace: [dq scratch fp32 (bh*n*d)] [nlse (bh*n)] [ndelta (bh*n)]
+size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
+    return sizeof(float) * ((size_t)bh * n * d + 2 * (size_t)bh * n) + 256;
+}
+
+template <typename Tag, int D>
+static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
+    constexpr int BK = 256;
+    const size_t nel = (size_t)a.bh * a.n * D;
+    const long long rows = (long long)a.bh * a.n;
+    float* dq_acc = reinterpret_cast<float*>(a.workspace);
+    float* nlse = dq_acc + nel;
+    float* ndelta = nlse + rows;
+    hipError_t e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    {
+        ProfScope ps(K_BWD_DELTA, st);
+        hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
+                           (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, D, 1.0f / a.scale);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nkt = (int)((a.n + BK - 1) / BK);
+    const size_t smem = (size_t)BK * D * 2 + 4 * 32 * D * 2 + BK * 32 * 2 + 2 * 64 * sizeof(float);
+    const float c = a.scale * 1.4426950408889634f;
+    dim3 grid((unsigned)(nkt * a.bh));
+    {
+        ProfScope ps(K_BWD_MFMA, st);
+        if (a.causal) {
+            auto kern = bwd_mfma_kernel<Tag, D, true>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                               (const uint16_t*)a.v, (const uint16_t*)a.dout, (const float*)nlse, (const float*)ndelta,
+                               dq_acc, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
+        } else {
+            auto kern = bwd_mfma_kernel<Tag, D, false>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                               (const uint16_t*)a.v, (const uint16_t*)a.dout, (const float*)nlse, (const float*)ndelta,
+                               dq_acc, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
+        }
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    {
+        ProfScope ps(K_BWD_DQ_CVT, st);
+        const long long n8 = (long long)(nel / 8);
+        hipLaunchKernelGGL(dq_convert_kernel<Tag>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
+                           (const float*)dq_acc, (uint16_t*)a.dq, n8, a.scale);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st) {
+    if (a.dtype == 2) return a.d == 128 ? launch_bwd_t<bf16_tag, 128>(a, st) : launch_bwd_t<bf16_tag, 64>(a, st);
+    return a.d == 128 ? launch_bwd_t<f16_tag, 128>(a, st) : launch_bwd_t<f16_tag, 64>(a, st);
+}
+
+}  // namespace fa

@@ -56,8 +56,14 @@ int check_common(const char* who, int64_t bh, int64_t n, int64_t d, int dtype, d
     return FA_OK;
 }
 
-bool use_mfma_fwd(int dtype, int64_t d) { return g_mode.load() == FA_MODE_AUTO && fa::fwd_mfma_supported(dtype, d); }
-bool use_mfma_bwd(int dtype, int64_t d) { return g_mode.load() == FA_MODE_AUTO && fa::bwd_mfma_supported(dtype, d); }
+// the 16-bit MFMA kernels fold softmax_scale into the exp2 argument and need it finite and > 0
+bool scale_ok(double s) { return s > 1e-20 && s < 1e20; }
+bool use_mfma_fwd(int dtype, int64_t d, double s) {
+    return g_mode.load() == FA_MODE_AUTO && scale_ok(s) && fa::fwd_mfma_supported(dtype, d);
+}
+bool use_mfma_bwd(int dtype, int64_t d, double s) {
+    return g_mode.load() == FA_MODE_AUTO && scale_ok(s) && fa::bwd_mfma_supported(dtype, d);
+}
 
 int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
                  int64_t n, int64_t d, int dtype, int causal, double scale, void* stream) {
@@ -67,7 +73,7 @@ int forward_impl(const char* who, const void* q, const void* k, const void* v, v
     if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", who);
     fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)scale};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = use_mfma_fwd(dtype, d) ? fa::launch_fwd_mfma(a, st) : fa::launch_fwd_generic(a, st);
+    hipError_t e = use_mfma_fwd(dtype, d, scale) ? fa::launch_fwd_mfma(a, st) : fa::launch_fwd_generic(a, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
     return FA_OK;
 }
@@ -85,7 +91,7 @@ int backward_impl(const char* who, const void* q, const void* k, const void* v, 
         return fail(FA_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, ws_bytes);
     fa::BwdArgs a{q, k, v, o, dout, lse, dq, dk, dv, bh, n, d, dtype, causal ? 1 : 0, (float)scale, ws, ws_bytes};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = use_mfma_bwd(dtype, d) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
+    hipError_t e = use_mfma_bwd(dtype, d, scale) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
     return FA_OK;
 }

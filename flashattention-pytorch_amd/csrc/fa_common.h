@@ -69,6 +69,22 @@ template <> __device__ __forceinline__ f32x16 mfma32<f16_tag>(s16x8 a, s16x8 b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8*>(&a), *reinterpret_cast<h8*>(&b), c, 0, 0, 0);
 }
 
+// Same MFMA with the accumulator pinned to the ARCHITECTURAL VGPR file (inline asm, "+v").
+// Why: in a kernel that needs more than 256 registers hipcc selects the AGPR form for every builtin MFMA, so
+// short-lived accumulators that VALU code consumes (S, dP, dQ tiles) would compete with the resident dK/dV
+// accumulators for the 256 AGPRs and bounce through v_accvgpr_read/write.  hipcc pads no hazards inside asm:
+// the leading s_nop 1 covers a VALU-written operand, and mfma_result_fence() must follow the last MFMA of a
+// chain before anything but a chained MFMA reads the result (8-pass XDL -> 12 wait states).
+template <typename Tag> __device__ __forceinline__ void mfma32_v(s16x8 a, s16x8 b, f32x16& c);
+template <> __device__ __forceinline__ void mfma32_v<bf16_tag>(s16x8 a, s16x8 b, f32x16& c) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma32_v<f16_tag>(s16x8 a, s16x8 b, f32x16& c) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_result_fence(f32x16& c) { asm volatile("s_nop 11" : "+v"(c)); }
+__device__ __forceinline__ void mfma_result_fence(f32x16& c, f32x16& d) { asm volatile("s_nop 11" : "+v"(c), "+v"(d)); }
+
 __device__ __forceinline__ float wave_half_swap(float x) {  // value held by lane ^ 32
     return __shfl_xor(x, 32, 64);
 }

@@ -1,0 +1,254 @@
+// FlashAttention forward for gfx950, 16-bit inputs (bf16 / f16), head_dim 64 or 128.
+//
+// Replaces the host tile loop of csrc/fa2/fa2_fwd.cu:56-103 (and fa1/fa3 siblings) with one fused kernel:
+// S = QK^T -> scale -> mask -> online softmax -> O += PV, fp32 accumulation, `o` in the input dtype, `lse` fp32.
+//
+// Decomposition (wave64, MFMA 32x32x16):
+//   workgroup = 8 waves = 256 query rows of one (b,h); each wave owns 32 query rows.
+//   K/V tiles of 64 keys are staged global -> registers -> LDS (XOR-swizzled rows, double buffered,
+//   one barrier per tile); Q stays in registers as the B operand.
+//   S^T = K . Q^T  ("swapped" product): the 32x32 accumulator then has the QUERY on the lane
+//   (col = lane & 31) and 16 keys per lane in registers, so the running max / sum of a query row are
+//   per-lane scalars: the row reductions are in-register plus one exchange with lane ^ 32.
+//   O^T += V^T . P^T : P^T is taken straight from the S^T accumulator registers (packed to 16 bit) as the
+//   B operand — an accumulator tile used as the next MFMA's operand — and V^T comes from the row-major V tile
+//   through the transposing LDS read ds_read_b64_tr_b16.  O^T again has the query on the lane, so the
+//   online-softmax rescale is a per-lane scalar multiply.
+//
+// Accumulator layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+// byte offset of 16-byte chunk `ch` of row `row` inside a [rows][D] 16-bit LDS tile.
+// Conflict-free both for the row-wise ds_read_b128 operand reads (lanes = 32 different rows, same chunk) and
+// for the transposed ds_read_b64_tr_b16 reads (4 rows x 64 B per half wave).
+template <int D> struct TileSwz;
+template <> struct TileSwz<128> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+};
+template <> struct TileSwz<64> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
+};
+
+typedef short lds_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                          const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                          float* __restrict__ lse, int n, int nqt, float c_log2,
+                                                          float scale) {
+    constexpr int BM = 256, BN = 64, NKS = D / 16, NDV = D / 32, CPR = D / 8;
+    constexpr int TILE_BYTES = BN * D * 2, LPT = (BN * CPR) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;  // heaviest query tiles first
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][16 ks + 8 h .. +7]
+    s16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (qrow < n) t = *reinterpret_cast<const u32x4*>(q + base + (size_t)qrow * D + 16 * ks + 8 * h);
+        qf[ks] = *reinterpret_cast<s16x8*>(&t);
+    }
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+
+    // staging assignment: thread -> LPT chunks of 16 B per tile and tensor
+    int st_row[LPT], st_ch[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int c = tid + 512 * i;
+        st_row[i] = c / CPR;
+        st_ch[i] = c - st_row[i] * CPR;
+    }
+    u32x4 kreg[LPT], vreg[LPT];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int key = k0 + st_row[i];
+            kreg[i] = u32x4{0u, 0u, 0u, 0u};
+            vreg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (key < n) {
+                const size_t g = base + (size_t)key * D + 8 * st_ch[i];
+                kreg[i] = *reinterpret_cast<const u32x4*>(k + g);
+                vreg[i] = *reinterpret_cast<const u32x4*>(v + g);
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* kb_ = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int off = TileSwz<D>::off(st_row[i], st_ch[i]);
+            *reinterpret_cast<u32x4*>(kb_ + off) = kreg[i];
+            *reinterpret_cast<u32x4*>(kb_ + TILE_BYTES + off) = vreg[i];
+        }
+    };
+
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    float m_run = -INFINITY;  // running max of the raw scores (before softmax_scale) of this lane's query row
+    float l_run = 0.f;        // this half-wave's share of the running sum
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    // lane-constant pieces of the transposed V read address
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * BN;
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage_load(k0 + BN);
+
+        const char* Kt = smem + cur * 2 * TILE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+        // a wave whose 32 rows all lie above this tile's first key has nothing to do (causal)
+        const bool active = !CAUSAL || (k0 <= q0 + 32 * w + 31);
+        if (active) {
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
+                    sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
+                }
+            }
+            // ---- mask (diagonal tiles / ragged last tile only)
+            const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= n || (CAUSAL && key > qrow)) sacc[kb][i] = -INFINITY;
+                    }
+            }
+            // ---- online softmax for query row `qrow` (per lane; the other 32 keys live in lane ^ 32)
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[1][i]);
+            mx = fmaxf(mx, wave_half_swap(mx));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
+            const float mc = m_use * c_log2;
+            m_run = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
+                    sacc[kb][i] = p;
+                    rs += p;
+                }
+            l_run = l_run * alpha + rs;
+#pragma unroll
+            for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    u32x4 pk;
+                    pk[0] = pack2<Tag>(sacc[kb][8 * s + 0], sacc[kb][8 * s + 1]);
+                    pk[1] = pack2<Tag>(sacc[kb][8 * s + 2], sacc[kb][8 * s + 3]);
+                    pk[2] = pack2<Tag>(sacc[kb][8 * s + 4], sacc[kb][8 * s + 5]);
+                    pk[3] = pack2<Tag>(sacc[kb][8 * s + 6], sacc[kb][8 * s + 7]);
+                    const s16x8 pb = *reinterpret_cast<s16x8*>(&pk);
+                    const int key_a = 32 * kb + 16 * s + 4 * h + tq;  // rows of the first 4-row block; second is +8
+#pragma unroll
+                    for (int dvb = 0; dvb < NDV; ++dvb) {
+                        const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+                        const s16x4 lo = lds_read_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1));
+                        const s16x4 hi = lds_read_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1));
+                        const s16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+                    }
+                }
+            }
+        }
+        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, store O (input dtype) and lse (fp32, natural log)
+    const float l_tot = l_run + wave_half_swap(l_run);
+    if (qrow < n) {
+        const float inv = 1.f / l_tot;
+        uint16_t* orow = o + base + (size_t)qrow * D;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
+                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * g + 4 * h) = pk;
+            }
+        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+    }
+}
+
+bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
+
+template <typename Tag, int D>
+static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
+    constexpr int BM = 256;
+    const int nqt = (int)((a.n + BM - 1) / BM);
+    const size_t smem = 2 * 2 * 64 * D * 2;
+    const float c = a.scale * 1.4426950408889634f;
+    dim3 grid((unsigned)(nqt * a.bh));
+    ProfScope ps(K_FWD_MFMA, st);
+    if (a.causal) {
+        auto kern = fwd_mfma_kernel<Tag, D, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
+    } else {
+        auto kern = fwd_mfma_kernel<Tag, D, false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
+    if (a.dtype == 2) return a.d == 128 ? launch_fwd_t<bf16_tag, 128>(a, st) : launch_fwd_t<bf16_tag, 64>(a, st);
+    return a.d == 128 ? launch_fwd_t<f16_tag, 128>(a, st) : launch_fwd_t<f16_tag, 64>(a, st);
+}
+
+}  // namespace fa
