@@ -1,0 +1,180 @@
+// FlashAttention backward, dQ pass, for gfx950 (bf16 / f16, head_dim 64 or 128).
+//
+//   dQ[q] = scale * sum_key dS[q][key] K[key],   dS = P * (dP - delta),  P = exp(S - lse),  dP = dO V^T
+//   (csrc/fa2/fa2_bwd.cu:91-103 restricted to the dQ accumulation; S and dP are recomputed here so that the
+//   backward needs no cross-workgroup sum: no atomics, bitwise reproducible.)
+//
+// Same decomposition as the forward kernel (fa_fwd_mfma.hip): workgroup = 8 waves = 256 query rows, each wave 32
+// rows; K and V tiles of 64 keys double-buffered in LDS.  Products are "swapped" so the QUERY sits on the lane:
+//   S^T  = K  Q^T    (A: K rows from LDS,  B: Q fragments in registers)   initial accumulator = -lse/scale
+//   dP^T = V dO^T    (A: V rows from LDS,  B: dO fragments in registers)  initial accumulator = -delta
+//   dS^T = exp2(c S'^T) * dP'^T          (row constants are per-lane scalars here)
+//   dQ^T += K^T dS^T (A: K^T by ds_read_b64_tr_b16, B: dS^T straight from the accumulator registers)
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                             const uint16_t* __restrict__ v,
+                                                             const uint16_t* __restrict__ dout,
+                                                             const float* __restrict__ nlse,
+                                                             const float* __restrict__ ndelta, uint16_t* __restrict__ dq,
+                                                             int n, int nqt, float c_log2, float scale) {
+    constexpr int BM = 256, BN = 64, NKS = D / 16, NDB = D / 32, CPR = D / 8;
+    constexpr int TILE_BYTES = BN * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+
+    s16x8 qf[NKS], of[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 t = {0u, 0u, 0u, 0u}, u = {0u, 0u, 0u, 0u};
+        if (qrow < n) {
+            t = *reinterpret_cast<const u32x4*>(q + base + (size_t)qrow * D + 16 * ks + 8 * h);
+            u = *reinterpret_cast<const u32x4*>(dout + base + (size_t)qrow * D + 16 * ks + 8 * h);
+        }
+        qf[ks] = *reinterpret_cast<s16x8*>(&t);
+        of[ks] = *reinterpret_cast<s16x8*>(&u);
+    }
+    // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
+    const float nl = qrow < n ? nlse[(size_t)bh * n + qrow] : -1e30f;
+    const float nd = qrow < n ? ndelta[(size_t)bh * n + qrow] : 0.f;
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+
+    // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
+    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w);
+    auto stage = [&](int buf, int k0) {
+        char* kb_ = smem + buf * 2 * TILE_BYTES;
+        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w);
+    };
+
+    f32x16 dqa[NDB];
+#pragma unroll
+    for (int t = 0; t < NDB; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+    // tiles this wave computes: under the causal mask a tile whose first key lies past the wave's last row is
+    // skipped.  Two loops instead of an `if` inside one: a conditional accumulate makes hipcc carry the
+    // accumulators through copies.
+    const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
+    for (int t = 0; t < ntiles_w; ++t) {
+        const int k0 = t * BN;
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);  // nobody reads that buffer: all waves passed the last barrier
+        const char* Kt = smem + cur * 2 * TILE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+        {
+            u32x4 dsb[2][2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sacc[i] = nl; pacc[i] = nd; }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int off = TileSwz<D>::off(32 * kb + r, 2 * ks + h);
+                    const s16x8 ka = *reinterpret_cast<const s16x8*>(Kt + off);
+                    sacc = mfma32<Tag>(ka, qf[ks], sacc);
+                    const s16x8 va = *reinterpret_cast<const s16x8*>(Vt + off);
+                    pacc = mfma32<Tag>(va, of[ks], pacc);
+                }
+                const bool need_mask = (CAUSAL && (k0 + 32 * kb + 31 > q0 + 32 * w)) || (k0 + 32 * kb + 32 > n);
+                // register i holds key k0 + 32 kb + 4 h + rc(i): one per-lane threshold, no branch
+                const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+                const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                    pacc[i] = ((i & 3) + 8 * (i >> 2) > thr) ? 0.f : p * pacc[i];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dsb[kb][s][j] = pack2<Tag>(pacc[8 * s + 2 * j], pacc[8 * s + 2 * j + 1]);
+                __builtin_amdgcn_sched_barrier(0);   // keep the two key blocks' operand prefetch apart (register budget)
+            }
+            // ---- dQ^T += K^T dS^T
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const s16x8 sb = *reinterpret_cast<s16x8*>(&dsb[kb][s]);
+                    const int key_a = 32 * kb + 16 * s + 4 * h + tq;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const int ch = 4 * db + 2 * g16 + (tp >> 1);
+                        const s16x8 a = cat8(lds_tr16(Kt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
+                                             lds_tr16(Kt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
+                        dqa[db] = mfma32<Tag>(a, sb, dqa[db]);
+                    }
+                }
+        }
+        __syncthreads();  // also drains this wave's LDS-DMA (vmcnt(0)) before the barrier
+    }
+    // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
+    for (int t = ntiles_w; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        __syncthreads();
+    }
+
+    if (qrow < n) {
+        uint16_t* drow = dq + base + (size_t)qrow * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(dqa[db][4 * g + 0] * scale, dqa[db][4 * g + 1] * scale);
+                pk[1] = pack2_rn<Tag>(dqa[db][4 * g + 2] * scale, dqa[db][4 * g + 3] * scale);
+                *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = pk;
+            }
+    }
+}
+
+template <typename Tag, int D>
+static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    constexpr int BM = 256;
+    const int nqt = (int)((a.n + BM - 1) / BM);
+    const size_t smem = 2 * 2 * 64 * D * 2;
+    const float c = a.scale * 1.4426950408889634f;
+    dim3 grid((unsigned)(nqt * a.bh));
+    ProfScope ps(K_BWD_DQ_MFMA, st);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                           (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
+                           a.scale);
+        return hipGetLastError();
+    };
+    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true>) : launch(bwd_dq_mfma_kernel<Tag, D, false>);
+}
+
+hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.dtype == 2) return a.d == 128 ? launch_dq_t<bf16_tag, 128>(a, nlse, ndelta, st) : launch_dq_t<bf16_tag, 64>(a, nlse, ndelta, st);
+    return a.d == 128 ? launch_dq_t<f16_tag, 128>(a, nlse, ndelta, st) : launch_dq_t<f16_tag, 64>(a, nlse, ndelta, st);
+}
+
+}  // namespace fa

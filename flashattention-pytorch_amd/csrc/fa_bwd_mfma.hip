@@ -25,24 +25,13 @@
 //   dSs [256 keys][32 q]  written 8 B per lane from the accumulators, read by columns (A operand of dQ)
 #include "fa_common.h"
 #include "fa_kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace fa {
 
-template <int D> struct TileSwzB;
-template <> struct TileSwzB<128> {
-    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
-};
-template <> struct TileSwzB<64> {
-    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
-};
 // dS^T image: 64-byte rows (32 queries), 8-byte slots
 __device__ __forceinline__ int ds_off(int key, int slot) { return 64 * key + 8 * (slot ^ ((key >> 1) & 7)); }
-
-typedef short lds_s16x4b __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4b __attribute__((address_space(3)))*)(p));
-}
-__device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // ------------------------------------------------------------------------------------------------
 template <typename Tag>
@@ -89,7 +78,7 @@ __global__ __launch_bounds__(256) void dq_convert_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool FUSED_DQ>
 __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v,
                                                           const uint16_t* __restrict__ dout,
@@ -123,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
         const int row = c / CPR, ch = c - row * CPR;
         u32x4 t = {0u, 0u, 0u, 0u};
         if (key0 + row < n) t = *reinterpret_cast<const u32x4*>(k + base + (size_t)(key0 + row) * D + 8 * ch);
-        *reinterpret_cast<u32x4*>(Ks + TileSwzB<D>::off(row, ch)) = t;
+        *reinterpret_cast<u32x4*>(Ks + TileSwz<D>::off(row, ch)) = t;
     }
     // ---- V fragments (B operand of dP = dO V^T): lane holds V[key][16 ks + 8 h .. +7] for its two key blocks
     s16x8 vf[2][NKS];
@@ -169,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int off = TileSwzB<D>::off(st_row[i], st_ch[i]);
+            const int off = TileSwz<D>::off(st_row[i], st_ch[i]);
             *reinterpret_cast<u32x4*>(Qs + buf * Q_BYTES + off) = qreg[i];
             *reinterpret_cast<u32x4*>(Os + buf * Q_BYTES + off) = oreg[i];
         }
@@ -219,10 +208,10 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                 }
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const s16x8 qa = *reinterpret_cast<const s16x8*>(Qt + TileSwzB<D>::off(r, 2 * ks + h));
-                    const s16x8 kbf = *reinterpret_cast<const s16x8*>(Ks + TileSwzB<D>::off(64 * w + 32 * kb + r, 2 * ks + h));
+                    const s16x8 qa = *reinterpret_cast<const s16x8*>(Qt + TileSwz<D>::off(r, 2 * ks + h));
+                    const s16x8 kbf = *reinterpret_cast<const s16x8*>(Ks + TileSwz<D>::off(64 * w + 32 * kb + r, 2 * ks + h));
                     mfma32_v<Tag>(qa, kbf, sacc);
-                    const s16x8 oa = *reinterpret_cast<const s16x8*>(Ot + TileSwzB<D>::off(r, 2 * ks + h));
+                    const s16x8 oa = *reinterpret_cast<const s16x8*>(Ot + TileSwz<D>::off(r, 2 * ks + h));
                     mfma32_v<Tag>(oa, vf[kb][ks], pacc);
                     if (D > 64 && (ks & 1)) __builtin_amdgcn_sched_barrier(0);   // bound the operand prefetch depth
                 }
@@ -230,15 +219,24 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- P = exp2(c S'), dS = P dP'; mask on diagonal / ragged blocks
                 const bool need_mask = (CAUSAL && (kw0 + 31 > qs)) || (kw0 + 32 > n);
+                if (need_mask) {
+                    // register i holds query qs + 4 h + rc(i); masked when that query precedes this lane's key
+                    // (causal) or the key lies past n: rc(i) < thr with one per-lane threshold
+                    const int key = key0 + kl;
+                    const int thr = key >= n ? 64 : (CAUSAL ? key - qs - 4 * h : -1);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
-                    if (need_mask) {
-                        const int qrow = qs + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key0 + kl >= n || (CAUSAL && key0 + kl > qrow)) p = 0.f;
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = ((i & 3) + 8 * (i >> 2) < thr) ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                        sacc[i] = p;
+                        pacc[i] = p * pacc[i];
                     }
-                    sacc[i] = p;
-                    pacc[i] = p * pacc[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                        sacc[i] = p;
+                        pacc[i] = p * pacc[i];
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -253,12 +251,14 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- dS^T -> LDS: lane (key kl) writes the 4 queries 8g + 4h .. +3 of register group g as 8 bytes
+            if (FUSED_DQ) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 t;
-                t[0] = sp[g >> 1][2 * (g & 1)];
-                t[1] = sp[g >> 1][2 * (g & 1) + 1];
-                *reinterpret_cast<u32x2*>(Ss + ds_off(kl, 2 * g + h)) = t;
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 t;
+                    t[0] = sp[g >> 1][2 * (g & 1)];
+                    t[1] = sp[g >> 1][2 * (g & 1) + 1];
+                    *reinterpret_cast<u32x2*>(Ss + ds_off(kl, 2 * g + h)) = t;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) {
                         const int ch = 4 * db + 2 * g16 + (tp >> 1);
-                        const int o1 = TileSwzB<D>::off(qa, ch) + 8 * (tp & 1);
-                        const int o2 = TileSwzB<D>::off(qa + 8, ch) + 8 * (tp & 1);
+                        const int o1 = TileSwz<D>::off(qa, ch) + 8 * (tp & 1);
+                        const int o2 = TileSwz<D>::off(qa + 8, ch) + 8 * (tp & 1);
                         const s16x8 doT = cat8(lds_tr16(Ot + o1), lds_tr16(Ot + o2));
                         dva[kb][db] = mfma32<Tag>(doT, pb, dva[kb][db]);
                         const s16x8 qT = cat8(lds_tr16(Qt + o1), lds_tr16(Qt + o2));
@@ -285,10 +285,10 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();  // dS^T of all 256 keys is in LDS
+        if (FUSED_DQ) __syncthreads();  // dS^T of all 256 keys is in LDS
 
         // ---- dQ tile (32 queries x 32 columns db_q) = sum over this wave's share of the 256 keys of dS K
-        {
+        if (FUSED_DQ) {
             f32x16 dqa;
 #pragma unroll
             for (int i = 0; i < 16; ++i) dqa[i] = 0.f;
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                 const int ka = kb16 + 4 * h + tq;
                 const s16x8 a = cat8(lds_tr16(Ss + ds_off(ka, 4 * g16 + tp)), lds_tr16(Ss + ds_off(ka + 8, 4 * g16 + tp)));
                 const int ch = 4 * db_q + 2 * g16 + (tp >> 1);
-                const s16x8 b = cat8(lds_tr16(Ks + TileSwzB<D>::off(ka, ch) + 8 * (tp & 1)),
-                                     lds_tr16(Ks + TileSwzB<D>::off(ka + 8, ch) + 8 * (tp & 1)));
+                const s16x8 b = cat8(lds_tr16(Ks + TileSwz<D>::off(ka, ch) + 8 * (tp & 1)),
+                                     lds_tr16(Ks + TileSwz<D>::off(ka + 8, ch) + 8 * (tp & 1)));
                 mfma32_v<Tag>(a, b, dqa);
             }
             mfma_result_fence(dqa);
@@ -359,8 +359,12 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     float* dq_acc = reinterpret_cast<float*>(a.workspace);
     float* nlse = dq_acc + nel;
     float* ndelta = nlse + rows;
-    hipError_t e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
-    if (e != hipSuccess) return e;
+    const bool fused = a.fused_dq != 0;
+    hipError_t e = hipSuccess;
+    if (fused) {
+        e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
+        if (e != hipSuccess) return e;
+    }
     {
         ProfScope ps(K_BWD_DELTA, st);
         hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
@@ -374,24 +378,19 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(nkt * a.bh));
     {
         ProfScope ps(K_BWD_MFMA, st);
-        if (a.causal) {
-            auto kern = bwd_mfma_kernel<Tag, D, true>;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e2 != hipSuccess) return e2;
             hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                                (const uint16_t*)a.v, (const uint16_t*)a.dout, (const float*)nlse, (const float*)ndelta,
                                dq_acc, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
-        } else {
-            auto kern = bwd_mfma_kernel<Tag, D, false>;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                               (const uint16_t*)a.v, (const uint16_t*)a.dout, (const float*)nlse, (const float*)ndelta,
-                               dq_acc, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
-        }
+            return hipGetLastError();
+        };
+        if (fused) e = a.causal ? launch(bwd_mfma_kernel<Tag, D, true, true>) : launch(bwd_mfma_kernel<Tag, D, false, true>);
+        else e = a.causal ? launch(bwd_mfma_kernel<Tag, D, true, false>) : launch(bwd_mfma_kernel<Tag, D, false, false>);
     }
-    e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (!fused) return launch_bwd_dq_mfma(a, nlse, ndelta, st);
     {
         ProfScope ps(K_BWD_DQ_CVT, st);
         const long long n8 = (long long)(nel / 8);

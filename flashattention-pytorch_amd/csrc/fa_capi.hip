@@ -10,6 +10,7 @@
 #include <vector>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -25,7 +26,7 @@ std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_free;
 hipEvent_t g_prof_open[fa::K_COUNT];
 const char* const kKernelNames[fa::K_COUNT] = {"fwd_f32", "bwd_delta", "bwd_dkdv_f32", "bwd_dq_f32", "fwd_mfma",
-                                               "bwd_mfma", "bwd_dq_cvt", "fp8_quant", "fwd_fp8"};
+                                               "bwd_mfma", "bwd_dq_cvt", "bwd_dq_mfma", "fp8_quant", "fwd_fp8"};
 
 hipEvent_t prof_get_event() {
     if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
@@ -56,13 +57,20 @@ int check_common(const char* who, int64_t bh, int64_t n, int64_t d, int dtype, d
     return FA_OK;
 }
 
+// FA_MODE_BWD_ATOMIC (or the environment variable FA_BWD_VARIANT=atomic) selects the single-kernel backward whose
+// dQ tiles are summed with global float atomics (5 GEMMs, not bitwise reproducible); the default is the split
+// backward: dK/dV kernel + dQ kernel (7 GEMMs, no atomics, deterministic).
+bool bwd_atomic_variant() {
+    static const int env = [] { const char* e = getenv("FA_BWD_VARIANT"); return (e && !strcmp(e, "atomic")) ? 1 : 0; }();
+    return env != 0 || g_mode.load() == FA_MODE_BWD_ATOMIC;
+}
 // the 16-bit MFMA kernels fold softmax_scale into the exp2 argument and need it finite and > 0
 bool scale_ok(double s) { return s > 1e-20 && s < 1e20; }
 bool use_mfma_fwd(int dtype, int64_t d, double s) {
-    return g_mode.load() == FA_MODE_AUTO && scale_ok(s) && fa::fwd_mfma_supported(dtype, d);
+    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && fa::fwd_mfma_supported(dtype, d);
 }
 bool use_mfma_bwd(int dtype, int64_t d, double s) {
-    return g_mode.load() == FA_MODE_AUTO && scale_ok(s) && fa::bwd_mfma_supported(dtype, d);
+    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && fa::bwd_mfma_supported(dtype, d);
 }
 
 int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
@@ -89,7 +97,8 @@ int backward_impl(const char* who, const void* q, const void* k, const void* v, 
     const size_t need = fa_backward_workspace_bytes(bh, n, d, dtype);
     if (!ws || ws_bytes < need)
         return fail(FA_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, ws_bytes);
-    fa::BwdArgs a{q, k, v, o, dout, lse, dq, dk, dv, bh, n, d, dtype, causal ? 1 : 0, (float)scale, ws, ws_bytes};
+    fa::BwdArgs a{q, k, v, o, dout, lse, dq, dk, dv, bh, n, d, dtype, causal ? 1 : 0, (float)scale, ws, ws_bytes,
+                   bwd_atomic_variant() ? 1 : 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = use_mfma_bwd(dtype, d, scale) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
@@ -229,7 +238,7 @@ const char* fa_last_error(void) { return g_err; }
 const char* fa_version(void) { return "fa_mi355x 0.1.0 (gfx950)"; }
 
 int fa_set_kernel_mode(int mode) {
-    if (mode != FA_MODE_AUTO && mode != FA_MODE_F32_GENERIC) return fail(FA_ERR_INVALID_ARGUMENT, "fa_set_kernel_mode: bad mode %d", mode);
+    if (mode != FA_MODE_AUTO && mode != FA_MODE_F32_GENERIC && mode != FA_MODE_BWD_ATOMIC) return fail(FA_ERR_INVALID_ARGUMENT, "fa_set_kernel_mode: bad mode %d", mode);
     return g_mode.exchange(mode);
 }
 

@@ -89,6 +89,57 @@ __device__ __forceinline__ float wave_half_swap(float x) {  // value held by lan
     return __shfl_xor(x, 32, 64);
 }
 
+// ---- LDS tile images ---------------------------------------------------------------------------
+// Byte offset of 16-byte chunk `ch` of row `row` inside a [rows][D] 16-bit LDS tile.  One image serves both kinds
+// of MFMA operand read and is conflict-free for each:
+//   * row-wise ds_read_b128 (32 lanes = 32 different rows, same chunk),
+//   * transposed ds_read_b64_tr_b16 (per half wave: 4 consecutive rows x 64 B).
+template <int D> struct TileSwz;
+template <> struct TileSwz<128> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+};
+template <> struct TileSwz<64> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
+};
+typedef short lds_s16x4_t __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major
+// (lane i of the group gets column i of the 4 rows; lane 4q+p supplies the address of row q, columns 4p..4p+3).
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// ---- LDS-DMA staging of a swizzled tile -----------------------------------------------------------
+// buffer_load_dwordx4 ... lds writes LDS at (wave-uniform base) + 16 * lane, so the LDS image stays lane-linear
+// and the XOR swizzle is applied to the per-lane SOURCE address instead: slot s of a row holds chunk s ^ f(row),
+// and f is its own inverse.  One wave-instruction moves 1 KiB = RPP = 512 / D rows.  Wave w of NW issues pieces
+// w, w + NW, ...; RPP * NW is a multiple of 16 rows, so f(row) is the same for every piece of a wave and the
+// per-lane offset is computed once.  Rows past the tensor's end read as zero through the buffer range check.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int D>
+__device__ __forceinline__ int dma_lane_voff(int lane, int w) {
+    constexpr int RPP = 512 / D, CPR = D / 8;
+    const int rl = lane / CPR, slot = lane - rl * CPR;
+    const int row = (RPP * w + rl) & 15;
+    const int ch = (TileSwz<D>::off(row, slot) - 2 * D * row) >> 4;
+    return rl * 2 * D + 16 * ch;
+}
+// stage rows [row0, row0 + ROWS) of the tensor behind `rsrc` (row stride 2*D bytes) into the LDS tile at `tile`
+template <int D, int ROWS, int NW>
+__device__ __forceinline__ void dma_stage_tile(buf_rsrc_t rsrc, char* tile, int row0, int voff, int w) {
+    constexpr int RPP = 512 / D, PIECES = ROWS / RPP, PER_WAVE = PIECES / NW;
+    static_assert(PIECES % NW == 0 && (RPP * NW) % 16 == 0, "tile does not split evenly over the waves");
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int pc = w + NW * j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + pc * 1024), 16, voff,
+                                                 (row0 + RPP * pc) * 2 * D, 0, 0);
+    }
+}
+
 // XCD-aware block remap: blocks that share blockIdx % 8 share an XCD (and its L2) under the
 // observed round-robin placement (speed only, never correctness).  Returns the logical id such that
 // consecutive logical ids [c*per, (c+1)*per) run on one XCD.  Bijective for any nblk.

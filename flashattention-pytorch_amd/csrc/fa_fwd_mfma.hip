@@ -21,30 +21,13 @@
 
 namespace fa {
 
-// byte offset of 16-byte chunk `ch` of row `row` inside a [rows][D] 16-bit LDS tile.
-// Conflict-free both for the row-wise ds_read_b128 operand reads (lanes = 32 different rows, same chunk) and
-// for the transposed ds_read_b64_tr_b16 reads (4 rows x 64 B per half wave).
-template <int D> struct TileSwz;
-template <> struct TileSwz<128> {
-    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
-};
-template <> struct TileSwz<64> {
-    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
-};
-
-typedef short lds_s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ s16x4 lds_read_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 __attribute__((address_space(3)))*)(p));
-}
-
 template <typename Tag, int D, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
                                                           float scale) {
     constexpr int BM = 256, BN = 64, NKS = D / 16, NDV = D / 32, CPR = D / 8;
-    constexpr int TILE_BYTES = BN * D * 2, LPT = (BN * CPR) / 512;
+    constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -69,36 +52,14 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     const int kend = CAUSAL ? min(n, q0 + BM) : n;
     const int ntiles = (kend + BN - 1) / BN;
 
-    // staging assignment: thread -> LPT chunks of 16 B per tile and tensor
-    int st_row[LPT], st_ch[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int c = tid + 512 * i;
-        st_row[i] = c / CPR;
-        st_ch[i] = c - st_row[i] * CPR;
-    }
-    u32x4 kreg[LPT], vreg[LPT];
-    auto stage_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int key = k0 + st_row[i];
-            kreg[i] = u32x4{0u, 0u, 0u, 0u};
-            vreg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (key < n) {
-                const size_t g = base + (size_t)key * D + 8 * st_ch[i];
-                kreg[i] = *reinterpret_cast<const u32x4*>(k + g);
-                vreg[i] = *reinterpret_cast<const u32x4*>(v + g);
-            }
-        }
-    };
-    auto stage_write = [&](int buf) {
+    // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
+    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w);
+    auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int off = TileSwz<D>::off(st_row[i], st_ch[i]);
-            *reinterpret_cast<u32x4*>(kb_ + off) = kreg[i];
-            *reinterpret_cast<u32x4*>(kb_ + TILE_BYTES + off) = vreg[i];
-        }
+        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w);
     };
 
     f32x16 oacc[NDV];
@@ -109,23 +70,24 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     float m_run = -INFINITY;  // running max of the raw scores (before softmax_scale) of this lane's query row
     float l_run = 0.f;        // this half-wave's share of the running sum
 
-    stage_load(0);
-    stage_write(0);
+    stage(0, 0);
     __syncthreads();
 
     // lane-constant pieces of the transposed V read address
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
 
-    for (int t = 0; t < ntiles; ++t) {
+    // tiles this wave computes: under the causal mask a tile whose first key lies past the wave's last row is
+    // skipped.  Two loops instead of an `if` inside one: a conditional accumulate makes hipcc carry the
+    // accumulators through copies.
+    const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
+    for (int t = 0; t < ntiles_w; ++t) {
         const int k0 = t * BN;
         const int cur = t & 1;
-        if (t + 1 < ntiles) stage_load(k0 + BN);
+        if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);  // nobody reads that buffer: all waves passed the last barrier
 
         const char* Kt = smem + cur * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
-        // a wave whose 32 rows all lie above this tile's first key has nothing to do (causal)
-        const bool active = !CAUSAL || (k0 <= q0 + 32 * w + 31);
-        if (active) {
+        {
             f32x16 sacc[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -140,13 +102,16 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             // ---- mask (diagonal tiles / ragged last tile only)
             const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
             if (need_mask) {
+                // key index of register i is k0 + 32 kb + 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2): compare the
+                // compile-time rc(i) with one per-lane threshold instead of materialising every key index
+                const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;   // last visible key of this lane's row
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int thr = lim - (k0 + 32 * kb + 4 * h);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = k0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key >= n || (CAUSAL && key > qrow)) sacc[kb][i] = -INFINITY;
-                    }
+                    for (int i = 0; i < 16; ++i)
+                        if ((i & 3) + 8 * (i >> 2) > thr) sacc[kb][i] = -INFINITY;
+                }
             }
             // ---- online softmax for query row `qrow` (per lane; the other 32 keys live in lane ^ 32)
             float mx = sacc[0][0];
@@ -190,15 +155,19 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 #pragma unroll
                     for (int dvb = 0; dvb < NDV; ++dvb) {
                         const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
-                        const s16x4 lo = lds_read_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1));
-                        const s16x4 hi = lds_read_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1));
-                        const s16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const s16x4 lo = lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1));
+                        const s16x4 hi = lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1));
+                        const s16x8 a = cat8(lo, hi);
                         oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
                     }
                 }
             }
         }
-        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();  // also drains this wave's LDS-DMA (vmcnt(0)) before the barrier
+    }
+    // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
+    for (int t = ntiles_w; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
         __syncthreads();
     }
 

@@ -26,11 +26,12 @@ struct BwdArgs {
     float scale;
     void* workspace;
     size_t workspace_bytes;
+    int fused_dq;  // 1: single kernel, dQ by global float atomics; 0: dK/dV kernel + dQ kernel (deterministic)
 };
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
 // roofline figure; off by default, costs nothing when off).
-enum KernelId { K_FWD_F32 = 0, K_BWD_DELTA, K_BWD_DKDV_F32, K_BWD_DQ_F32, K_FWD_MFMA, K_BWD_MFMA, K_BWD_DQ_CVT,
+enum KernelId { K_FWD_F32 = 0, K_BWD_DELTA, K_BWD_DKDV_F32, K_BWD_DQ_F32, K_FWD_MFMA, K_BWD_MFMA, K_BWD_DQ_CVT, K_BWD_DQ_MFMA,
                 K_FP8_QUANT, K_FWD_FP8, K_COUNT };
 void prof_begin(int id, hipStream_t st);
 void prof_end(int id, hipStream_t st);
@@ -51,6 +52,7 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st);
 bool bwd_mfma_supported(int dtype, int64_t d);
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d);
+hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);
 
 // FA3-style fp8 forward (fa_fwd_fp8.hip): Q/K quantised to e4m3 per 64-row block, S on the fp8 MFMA
 bool fwd_fp8_supported(int dtype, int64_t d);

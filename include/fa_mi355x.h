@@ -53,6 +53,7 @@ extern "C" {
  * when dtype is 16-bit and d is 64 or 128, exact-f32 MFMA kernels otherwise. */
 #define FA_MODE_AUTO 0
 #define FA_MODE_F32_GENERIC 1
+#define FA_MODE_BWD_ATOMIC 2 /* as AUTO, but the 16-bit backward is the single-kernel variant with float-atomic dQ */
 
 /* --- FlashAttention-1 names (replaces csrc/fa1/fa1_fwd.cu:30, csrc/fa1/fa1_bwd.cu:30) --- */
 int fa1_forward(const void* q, const void* k, const void* v, void* o, float* lse,

@@ -58,6 +58,7 @@ def test_workspace_query_and_argument_validation_without_gpu():
     rc = lib.fa2_forward(None, None, None, None, None, 0, 8, 64, 2, 0, 0.125, 128, 128, None)
     assert rc == 0  # empty problem is a no-op
     assert lib.fa_set_kernel_mode(5) == -1
+    assert lib.fa_set_kernel_mode(2) == 0 and lib.fa_set_kernel_mode(0) == 2
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3])

@@ -88,9 +88,13 @@ def test_headline_shape_bf16_max_abs_error(causal, device):
     o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
     if not causal:
         assert max_abs(o.cpu().float(), ro) < 1e-3
-    else:  # early causal rows average few keys -> |o| ~ 1, bf16 output rounding is 2^-9 relative and P (bf16) adds as much
-        err = (o.cpu().double() - ro.double()).abs()
-        assert (err <= 1e-3 + 2.0 ** -7 * ro.double().abs()).all()
+    else:
+        # the first causal rows average only a few keys: |o| ~ |v| and cancellation make an absolute 1e-3 bar
+        # meaningless there (bf16 rounding of P alone is 2^-9 * sum p|v|); hold them to the reference's bf16 bar
+        # and the rows that average >= 64 keys to 1e-3 + one bf16 ulp of the result
+        torch.testing.assert_close(o.cpu().float(), ro.float(), rtol=5e-2, atol=5e-2)
+        err = (o.cpu().double() - ro.double()).abs()[:, 64:]
+        assert (err <= 1e-3 + 2.0 ** -8 * ro.double().abs()[:, 64:]).all()
     assert max_abs(lse.cpu(), rlse) < 1e-3
     for a, b in ((dq, rq), (dk, rk), (dv, rv)):
         torch.testing.assert_close(a.cpu().float(), b, rtol=5e-2, atol=5e-2)
@@ -243,3 +247,27 @@ def test_generic_and_mfma_paths_agree(causal, device):
     assert max_abs(lse_a, lse_b) < 1e-3
     for a, b in ((dq_a, dq_b), (dk_a, dk_b), (dv_a, dv_b)):
         torch.testing.assert_close(a.float(), b.float(), rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+def test_backward_variants_agree_and_split_is_deterministic(causal, d, device):
+    """Default backward = dK/dV kernel + dQ kernel (no atomics): bitwise reproducible.  The single-kernel variant
+    (dQ summed with float atomics, FA_MODE_BWD_ATOMIC) must agree with it to rounding."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = (t.to(device) for t in make_qkv(3, 777, d, torch.bfloat16, seed=21))
+    a1 = _run(2, q, k, v, causal, d ** -0.5, do=do)
+    a2 = _run(2, q, k, v, causal, d ** -0.5, do=do)
+    for x, y in zip(a1, a2):
+        assert torch.equal(x, y)
+    old = ext.set_kernel_mode(2)
+    try:
+        b = _run(2, q, k, v, causal, d ** -0.5, do=do)
+    finally:
+        ext.set_kernel_mode(old)
+    for x, y in zip(a1[2:], b[2:]):
+        torch.testing.assert_close(x.float(), y.float(), rtol=2e-2, atol=2e-2)
+    rq, rk, rv, _, _ = orc.exact_attention_backward(q.cpu(), k.cpu(), v.cpu(), do.cpu(), causal, d ** -0.5, math_dtype=torch.float64)
+    for x, y in zip(b[2:], (rq, rk, rv)):
+        torch.testing.assert_close(x.cpu(), y, rtol=5e-2, atol=5e-2)
