@@ -1,0 +1,222 @@
+// FlashAttention backward, dK/dV pass, for gfx950 (bf16 / f16, head_dim 64 or 128) — two waves per SIMD.
+//
+//   dV[key] = sum_q P[q][key] dO[q],   dK[key] = scale * sum_q dS[q][key] Q[q]
+//   P = exp(S - lse), dS = P * (dO V^T - delta)            (csrc/fa2/fa2_bwd.cu:91-104, the dK/dV half)
+//
+// workgroup = 8 waves = 256 keys of one (b,h); wave w owns keys key0 + 32 w .. + 31 and keeps their dK^T and dV^T
+// (2 x D/32 accumulator tiles = 128 registers at D = 128) plus its V rows (B operand of dP) in registers; its K
+// rows (B operand of S) live in the workgroup's K tile in LDS.  Q and dO arrive in tiles of 64 query rows by
+// LDS-DMA, double buffered, one barrier per tile; every tile is read by rows (A operands of S and dP) and by
+// columns through ds_read_b64_tr_b16 (A operands of dV^T += dO^T P and dK^T += Q^T dS).
+// "Key on the lane": S[q][key] and dP[q][key] have the key as accumulator column, so P and dS feed the dV^T / dK^T
+// products straight from the accumulator registers, and -lse/scale, -delta enter as the initial accumulators.
+#include "fa_common.h"
+#include "fa_kernels.h"
+
+namespace fa {
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ v,
+                                                               const uint16_t* __restrict__ dout,
+                                                               const float* __restrict__ nlse,
+                                                               const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
+                                                               uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
+                                                               float scale) {
+    constexpr int BK = 256, BQ = 64, NKS = D / 16, NDB = D / 32, CPR = D / 8;
+    constexpr int K_BYTES = BK * D * 2, Q_BYTES = BQ * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                      // [256][D]
+    char* Qs = Ks + K_BYTES;              // [2][64][D]
+    char* Os = Qs + 2 * Q_BYTES;          // [2][64][D]   (dO)
+    float* Ls = reinterpret_cast<float*>(Os + 2 * Q_BYTES);  // [2][ 64 x -lse/scale | 64 x -delta ]
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nkt;
+    const int kt = L - bh * nkt;          // under the causal mask key tile 0 is the heaviest and is launched first
+    const int key0 = kt * BK;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const size_t base = (size_t)bh * n * D;
+    const size_t rbase = (size_t)bh * n;
+    const int kw0 = key0 + 32 * w;        // first key of this wave
+    const int key = kw0 + r;              // this lane's key
+
+    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
+    const buf_rsrc_t l_rs = make_rsrc(nlse + rbase, (unsigned)n * 4);
+    const buf_rsrc_t d_rs = make_rsrc(ndelta + rbase, (unsigned)n * 4);
+    const int dma_voff = dma_lane_voff<D>(lane, w);
+
+    auto stage = [&](int buf, int qs) {
+        dma_stage_tile<D, BQ, 8>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w);
+        dma_stage_tile<D, BQ, 8>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w);
+        // row constants: 64 floats each, one 4-byte LDS-DMA per lane (rows >= n read as 0: harmless, their dO is 0)
+        if (w == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(Ls + buf * 128), 4,
+                                                     lane * 4, qs * 4, 0, 0);
+        if (w == 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (__attribute__((address_space(3))) void*)(Ls + buf * 128 + 64), 4,
+                                                     lane * 4, qs * 4, 0, 0);
+    };
+
+    // ---- prologue: K tile by LDS-DMA, V fragments to registers, first Q/dO tile
+    dma_stage_tile<D, BK, 8>(k_rs, Ks, key0, dma_voff, w);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    s16x8 vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, (key * D + 16 * ks + 8 * h) * 2);
+    f32x16 dka[NDB], dva[NDB];
+#pragma unroll
+    for (int t = 0; t < NDB; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dka[t][i] = 0.f; dva[t][i] = 0.f; }
+
+    const int qs_first = CAUSAL ? (key0 / BQ) * BQ : 0;   // earlier query tiles see none of this workgroup's keys
+    const int ntile = (n - qs_first + BQ - 1) / BQ;
+    // first tile this wave computes: earlier tiles hold only queries before the wave's first key (causal)
+    const int it_first = CAUSAL ? (kw0 / BQ) - (qs_first / BQ) : 0;
+    stage(0, qs_first);
+    __syncthreads();
+
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+    // feed-only iterations (see fa_fwd_mfma.hip: two loops instead of a conditional accumulate)
+    for (int it = 0; it < min(it_first, ntile); ++it) {
+        if (it + 1 < ntile) stage((it & 1) ^ 1, qs_first + (it + 1) * BQ);
+        __syncthreads();
+    }
+    for (int it = it_first; it < ntile; ++it) {
+        const int qs = qs_first + it * BQ;
+        const int cur = it & 1;
+        if (it + 1 < ntile) stage(cur ^ 1, qs + BQ);
+        const char* Qt = Qs + cur * Q_BYTES;
+        const char* Ot = Os + cur * Q_BYTES;
+        const float* Lt = Ls + cur * 128;
+
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            // ---- S' = Q K^T - lse/scale (row constants as the initial accumulator), P = exp2(c S') packed to 16 bit,
+            // then dP' = dO V^T - delta and dS = P dP'.  One chain at a time: at D = 128 the wave has ~96 registers
+            // beside the resident dK^T / dV^T / V, and two live f32 tiles plus their operand prefetch do not fit.
+            // Register i holds query qs + 32 qb + 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2); it is masked when it
+            // precedes this lane's key (causal) or the key lies past n: rc(i) < thr, one per-lane threshold.
+            const bool need_mask = (CAUSAL && (kw0 + 31 > qs + 32 * qb)) || (kw0 + 32 > n);
+            const int thr = !need_mask ? -1 : (key >= n ? 64 : (CAUSAL ? key - (qs + 32 * qb) - 4 * h : -1));
+            // this wave's K rows sit 32 w rows into the K tile; the swizzle only depends on the row modulo 16, so
+            // the address is the Q row-read pattern plus a per-wave offset (recomputed per tile: saves 8 registers)
+            int kofs = 32 * w * 2 * D;
+            asm volatile("" : "+v"(kofs));
+            u32x4 pp[2], sp[2];
+            {
+                f32x16 sacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(Lt + 32 * qb + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc[4 * g + j] = a[j];
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int ro = TileSwz<D>::off(r, 2 * ks + h);
+                    const s16x8 qa = *reinterpret_cast<const s16x8*>(Qt + 32 * qb * 2 * D + ro);
+                    const s16x8 kf = *reinterpret_cast<const s16x8*>(Ks + ro + kofs);
+                    sacc = mfma32<Tag>(qa, kf, sacc);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    sacc[i] = ((i & 3) + 8 * (i >> 2) < thr) ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[s][j] = pack2<Tag>(sacc[8 * s + 2 * j], sacc[8 * s + 2 * j + 1]);
+            }
+            {
+                f32x16 pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(Lt + 64 + 32 * qb + 8 * g + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pacc[4 * g + j] = b[j];
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const s16x8 oa = *reinterpret_cast<const s16x8*>(Ot + 32 * qb * 2 * D + TileSwz<D>::off(r, 2 * ks + h));
+                    pacc = mfma32<Tag>(oa, vf[ks], pacc);
+                }
+                // dS = P dP' with the 16-bit P that also feeds dV (one rounding of P, shared by both products)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        sp[s][j] = pack2<Tag>(unpack_lo<Tag>(pp[s][j]) * pacc[8 * s + 2 * j],
+                                              unpack_hi<Tag>(pp[s][j]) * pacc[8 * s + 2 * j + 1]);
+            }
+            if (D > 64) __builtin_amdgcn_sched_barrier(0);
+            // ---- dV^T += dO^T P ,  dK^T += Q^T dS   (A operands: transposed reads of the dO / Q tiles)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[s]);
+                const s16x8 sb = *reinterpret_cast<s16x8*>(&sp[s]);
+                const int qa_ = 32 * qb + 16 * s + 4 * h + tq;   // rows (queries) of the first 4-row block; second is +8
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int ch = 4 * db + 2 * g16 + (tp >> 1);
+                    const int o1 = TileSwz<D>::off(qa_, ch) + 8 * (tp & 1);
+                    const int o2 = TileSwz<D>::off(qa_ + 8, ch) + 8 * (tp & 1);
+                    const s16x8 doT = cat8(lds_tr16(Ot + o1), lds_tr16(Ot + o2));
+                    dva[db] = mfma32<Tag>(doT, pb, dva[db]);
+                    const s16x8 qT = cat8(lds_tr16(Qt + o1), lds_tr16(Qt + o2));
+                    dka[db] = mfma32<Tag>(qT, sb, dka[db]);
+                }
+                if (D > 64) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)), then the barrier
+    }
+
+    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV
+    if (key < n) {
+        uint16_t* dkrow = dk + base + (size_t)key * D;
+        uint16_t* dvrow = dv + base + (size_t)key * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 a, b;
+                a[0] = pack2_rn<Tag>(dka[db][4 * g + 0] * scale, dka[db][4 * g + 1] * scale);
+                a[1] = pack2_rn<Tag>(dka[db][4 * g + 2] * scale, dka[db][4 * g + 3] * scale);
+                b[0] = pack2_rn<Tag>(dva[db][4 * g + 0], dva[db][4 * g + 1]);
+                b[1] = pack2_rn<Tag>(dva[db][4 * g + 2], dva[db][4 * g + 3]);
+                *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * h) = a;
+                *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * h) = b;
+            }
+    }
+}
+
+template <typename Tag, int D>
+static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    constexpr int BK = 256;
+    const int nkt = (int)((a.n + BK - 1) / BK);
+    const size_t smem = (size_t)BK * D * 2 + 4 * 64 * D * 2 + 2 * 128 * sizeof(float);
+    const float c = a.scale * 1.4426950408889634f;
+    dim3 grid((unsigned)(nkt * a.bh));
+    ProfScope ps(K_BWD_MFMA, st);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                           (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv,
+                           (int)a.n, nkt, c, a.scale);
+        return hipGetLastError();
+    };
+    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false>);
+}
+
+hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64>(a, nlse, ndelta, st);
+    return a.d == 128 ? launch_dkdv_t<f16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64>(a, nlse, ndelta, st);
+}
+
+}  // namespace fa

@@ -36,16 +36,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     const int qrow = q0 + 32 * w + r;
     const size_t base = (size_t)bh * n * D;
 
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
     s16x8 qf[NKS], of[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        u32x4 t = {0u, 0u, 0u, 0u}, u = {0u, 0u, 0u, 0u};
-        if (qrow < n) {
-            t = *reinterpret_cast<const u32x4*>(q + base + (size_t)qrow * D + 16 * ks + 8 * h);
-            u = *reinterpret_cast<const u32x4*>(dout + base + (size_t)qrow * D + 16 * ks + 8 * h);
-        }
-        qf[ks] = *reinterpret_cast<s16x8*>(&t);
-        of[ks] = *reinterpret_cast<s16x8*>(&u);
+        qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
+        of[ks] = buf_load_frag(o_rs, (qrow * D + 16 * ks + 8 * h) * 2);
     }
     // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
     const float nl = qrow < n ? nlse[(size_t)bh * n + qrow] : -1e30f;

@@ -213,10 +213,10 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                     mfma32_v<Tag>(qa, kbf, sacc);
                     const s16x8 oa = *reinterpret_cast<const s16x8*>(Ot + TileSwz<D>::off(r, 2 * ks + h));
                     mfma32_v<Tag>(oa, vf[kb][ks], pacc);
-                    if (D > 64 && (ks & 1)) __builtin_amdgcn_sched_barrier(0);   // bound the operand prefetch depth
+                    if (FUSED_DQ && D > 64 && (ks & 1)) __builtin_amdgcn_sched_barrier(0);   // bound the operand prefetch depth
                 }
                 mfma_result_fence(sacc, pacc);
-                __builtin_amdgcn_sched_barrier(0);
+                if (FUSED_DQ) __builtin_amdgcn_sched_barrier(0);
                 // ---- P = exp2(c S'), dS = P dP'; mask on diagonal / ragged blocks
                 const bool need_mask = (CAUSAL && (kw0 + 31 > qs)) || (kw0 + 32 > n);
                 if (need_mask) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { pp[s] = u32x4{0u, 0u, 0u, 0u}; sp[s] = u32x4{0u, 0u, 0u, 0u}; }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (FUSED_DQ) __builtin_amdgcn_sched_barrier(0);
             // ---- dS^T -> LDS: lane (key kl) writes the 4 queries 8g + 4h .. +3 of register group g as 8 bytes
             if (FUSED_DQ) {
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                     *reinterpret_cast<u32x2*>(Ss + ds_off(kl, 2 * g + h)) = t;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (FUSED_DQ) __builtin_amdgcn_sched_barrier(0);
             {
                 // ---- dV^T += dO^T P ,  dK^T += Q^T dS   (A operands: transposed reads of the dO / Q tiles).
                 // Unconditional on purpose: an inactive block (causal, before its diagonal) adds zeros.  Guarding
@@ -280,10 +280,10 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
                         const s16x8 qT = cat8(lds_tr16(Qt + o1), lds_tr16(Qt + o2));
                         dka[kb][db] = mfma32<Tag>(qT, sb, dka[kb][db]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (FUSED_DQ) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (FUSED_DQ) __builtin_amdgcn_sched_barrier(0);
         }
         if (FUSED_DQ) __syncthreads();  // dS^T of all 256 keys is in LDS
 
@@ -372,6 +372,14 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    // dK/dV pass of the split backward: the 8-wave kernel (two waves per SIMD) where its register budget holds
+    // is the default; FA_DKDV=w4 selects the 4-wave / 512-register kernel below (tile sweep evidence).
+    static const int dkdv_env = [] { const char* e = getenv("FA_DKDV"); return !e ? 0 : (!strcmp(e, "w8") ? 8 : (!strcmp(e, "w4") ? 4 : 0)); }();
+    if (!fused && dkdv_env != 4) {
+        e = launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
+        if (e != hipSuccess) return e;
+        return launch_bwd_dq_mfma(a, nlse, ndelta, st);
+    }
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * 32 * D * 2 + BK * 32 * 2 + 2 * 64 * sizeof(float);
     const float c = a.scale * 1.4426950408889634f;

@@ -31,9 +31,13 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(f
 // ---- packed 16-bit conversion (fast path); returns two 16-bit values in one dword, lo in bits 0..15 ----
 template <typename Tag> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack2<bf16_tag>(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    // Compiler-visible conversion (hipcc emits v_cvt_pk_bf16_f32 for it).  Do NOT hand-write the instruction in
+    // inline asm: hipcc pads no hazards around asm, and an asm VALU that reads an MFMA accumulator inside the
+    // MFMA's result latency gets stale data (seen as a rare wrong dV tile when the epilogue packed dV^T directly).
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
 }
 template <> __device__ __forceinline__ uint32_t pack2<f16_tag>(float lo, float hi) {
     __half2 v = __floats2half2_rn(lo, hi);
@@ -118,6 +122,11 @@ __device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shu
 typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
 __device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// 16 bytes at byte offset `off` of the tensor behind rsrc; zeros when the range check fails (rows past the end)
+__device__ __forceinline__ s16x8 buf_load_frag(buf_rsrc_t rsrc, int off) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    return *reinterpret_cast<s16x8*>(&t);
 }
 template <int D>
 __device__ __forceinline__ int dma_lane_voff(int lane, int w) {

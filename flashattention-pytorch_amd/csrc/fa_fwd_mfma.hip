@@ -41,13 +41,10 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     const size_t base = (size_t)bh * n * D;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][16 ks + 8 h .. +7]
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
     s16x8 qf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        u32x4 t = {0u, 0u, 0u, 0u};
-        if (qrow < n) t = *reinterpret_cast<const u32x4*>(q + base + (size_t)qrow * D + 16 * ks + 8 * h);
-        qf[ks] = *reinterpret_cast<s16x8*>(&t);
-    }
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
 
     const int kend = CAUSAL ? min(n, q0 + BM) : n;
     const int ntiles = (kend + BN - 1) / BN;

@@ -69,8 +69,9 @@ def test_hip_matches_oracle_on_seeded_inputs(bh, n, d, causal, dtype, device):
     tol = dtype_tolerances(dtype)
     torch.testing.assert_close(o.cpu(), ro, **tol)
     torch.testing.assert_close(lse.cpu(), rlse, rtol=1e-3, atol=1e-3)
-    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
-        torch.testing.assert_close(a.cpu(), b, **tol)
+    for name, a, b in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        bad = ((a.cpu().double() - b.double()).abs() > tol["atol"] + tol["rtol"] * b.double().abs()).any(dim=-1).nonzero()
+        assert len(bad) == 0, f"{name}: {len(bad)} bad rows, first {bad[:8].tolist()}, last {bad[-4:].tolist()}"
     if dtype == torch.float32:  # the exact-f32 kernels are far inside the 1e-4 bar
         assert max_abs(o.cpu(), ro) < 2e-5 and max_abs(lse.cpu(), rlse) < 2e-5
         assert max(max_abs(dq.cpu(), rq), max_abs(dk.cpu(), rk), max_abs(dv.cpu(), rv)) < 1e-4
