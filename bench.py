@@ -152,14 +152,15 @@ def main():
     # ---- separately timed RCCL all-gather of the outputs (rebuilds the full (B*world,H,N,d) tensors)
     gather_ms = None
     if dist is not None and not args.no_gather:
-        outs = [o.detach(), q.grad, k.grad, v.grad]
-        full = [torch.empty((world,) + t.shape, device=dev, dtype=t.dtype) for t in outs]
+        from common.shard import all_gather_bh
+
+        outs = [t.reshape(bh, N, D) for t in (o.detach(), q.grad, k.grad, v.grad)]
         for rep in range(3):
             torch.cuda.synchronize(); barrier(); t1 = time.perf_counter()
-            for t, f in zip(outs, full):
-                dist.all_gather_into_tensor(f, t.contiguous())
+            full = [all_gather_bh(t, bh * world) for t in outs]  # one fused RCCL all-gather per output
             torch.cuda.synchronize(); barrier()
             gather_ms = (time.perf_counter() - t1) * 1e3
+        del full
         tg = torch.tensor([gather_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_ms = tg.item()
@@ -167,21 +168,39 @@ def main():
     if rank == 0:
         total_flops = alg_flops(bh * world, N, D, args.causal, "fwd+bwd") * args.steps
         value = total_flops / elapsed / 1e12
-        # dominant kernel = the one with the largest total event time
-        kern = max(prof, key=lambda kname: prof[kname][1]) if prof else None
+        peak = PEAK_TFLOPS[args.dtype]
+        # algorithmic FLOPs per launch of each kernel (per (b,h): S, dP, dV, dK, dQ = 2*N^2*d each, x (N+1)/2N causal).
+        # The split backward prices its dK/dV kernel at the 4 products it alone is responsible for and the dQ kernel at
+        # the one product it adds; the S / dP it recomputes are overhead, not algorithmic work (DESIGN.md "Roofline").
+        gemm = alg_flops(bh, N, D, args.causal, "fwd") / 2.0
+        fused = os.environ.get("FA_BWD_VARIANT") == "atomic"
+        alg = {"fwd_mfma": 2 * gemm, "fwd_f32": 2 * gemm, "bwd_mfma": (5 if fused else 4) * gemm, "bwd_dq_mfma": gemm,
+               "bwd_dkdv_f32": 4 * gemm, "bwd_dq_f32": gemm}
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        default_cfg = (B, H, N, D, args.dtype, args.causal) == (8, 32, 4096, 128, "bf16", False) and not fused
+        if default_cfg and os.path.exists(tpath):  # PMC counters are collected in separate rocprofv3 --pmc passes
+            traffic = json.load(open(tpath))
+        kern = max((kname for kname in prof if kname in alg), key=lambda kname: prof[kname][1], default=None)
         roof = None
         if kern is not None:
             cnt, tot_ms = prof[kern]
-            direction = "fwd" if kern.startswith("fwd") else "bwd"
-            per_launch = alg_flops(bh, N, D, args.causal, direction)
-            if kern in ("bwd_dkdv_f32", "bwd_dq_f32"):
-                per_launch *= 0.5  # the exact-f32 backward is split in two kernels; each is priced at half of 10*N^2*d
-            ach = per_launch / (tot_ms / cnt * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.dtype]
+            ach = alg[kern] / (tot_ms / cnt * 1e-3) / 1e12
+            per_kernel = {}
+            for kname, (c_, ms_) in prof.items():
+                per_kernel[kname] = {"avg_launch_ms": round(ms_ / c_, 4)}
+                if kname in alg:
+                    per_kernel[kname]["achieved_tflops"] = round(alg[kname] / (ms_ / c_ * 1e-3) / 1e12, 1)
+                if kname in traffic:
+                    per_kernel[kname]["hbm_bytes"] = traffic[kname]["hbm_bytes"]
+            bwd_ms = sum(ms_ / c_ for kname, (c_, ms_) in prof.items() if kname.startswith("bwd"))
             roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(tot_ms / cnt, 4),
-                    "algorithmic_flop_per_launch": per_launch,
-                    "kernels_ms_per_step": {kname: round(v_[1] / max(1, args.steps), 4) for kname, v_ in prof.items()}}
+                    "frac": round(ach / peak, 4),
+                    "traffic": traffic.get(kern, {}).get("hbm_bytes"),
+                    "avg_launch_ms": round(tot_ms / cnt, 4), "algorithmic_flop_per_launch": alg[kern],
+                    "timing": "HIP events recorded on the launch stream around each kernel (fa_profile_enable)",
+                    "kernels": per_kernel,
+                    "backward_all_kernels_tflops": round(5 * gemm / (bwd_ms * 1e-3) / 1e12, 1) if bwd_ms > 0 else None}
         cpu = None
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(N, D, dtype, args.causal, args.cpu_seconds)
@@ -195,7 +214,7 @@ def main():
                        "global_batch": B * world, "heads": H, "seq_len": N, "head_dim": D, "causal": args.causal,
                        "parallelism": f"(b,h)-shard x{world}, no data-path collective"},
             "per_gpu_tflops": round(value / world, 2),
-            "frac_of_peak_per_gpu": round(value / world / PEAK_TFLOPS[args.dtype], 4),
+            "frac_of_peak_per_gpu": round(value / world / peak, 4),
             "reference_convention_tflops": round(8.0 * bh * world * N * N * D * args.steps / elapsed / 1e12, 2),
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "roofline": roof, "cpu_baseline": cpu,
