@@ -18,15 +18,16 @@
 // Accumulator layout of v_mfma_f32_32x32x16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #include "fa_common.h"
 #include "fa_kernels.h"
+#include <cstdlib>
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, int KB>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
                                                           float scale) {
-    constexpr int BM = 256, BN = 64, NKS = D / 16, NDV = D / 32, CPR = D / 8;
+    constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
         const char* Kt = smem + cur * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
         {
-            f32x16 sacc[2];
+            f32x16 sacc[KB];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                 // compile-time rc(i) with one per-lane threshold instead of materialising every key index
                 const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;   // last visible key of this lane's row
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < KB; ++kb) {
                     const int thr = lim - (k0 + 32 * kb + 4 * h);
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             // ---- online softmax for query row `qrow` (per lane; the other 32 keys live in lane ^ 32)
             float mx = sacc[0][0];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[0][i]);
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[1][i]);
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
             mx = fmaxf(mx, wave_half_swap(mx));
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             m_run = m_new;
             float rs = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 
             // ---- O^T += V^T P^T
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     u32x4 pk;
@@ -188,33 +189,42 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 
 bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
 
-template <typename Tag, int D>
+// K/V tile size in 32-key blocks: 4 (128 keys) is the measured winner (profiles/r01_tile_sweep.md);
+// FA_FWD_KB=1|2|4 overrides it for the sweep (1 only at d = 128).
+static int fwd_kb_override() {
+    static const int v = [] { const char* e = getenv("FA_FWD_KB"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+template <typename Tag, int D, int KB>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     const int nqt = (int)((a.n + BM - 1) / BM);
-    const size_t smem = 2 * 2 * 64 * D * 2;
+    const size_t smem = 2 * 2 * (32 * KB) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_MFMA, st);
-    if (a.causal) {
-        auto kern = fwd_mfma_kernel<Tag, D, true>;
+    auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
-    } else {
-        auto kern = fwd_mfma_kernel<Tag, D, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
-    }
-    return hipGetLastError();
+        return hipGetLastError();
+    };
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB>) : launch(fwd_mfma_kernel<Tag, D, false, KB>);
+}
+
+template <typename Tag, int D>
+static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
+    const int kb = fwd_kb_override();
+    if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
+    if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
+    return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key, LDS 128 KiB at d = 128
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
-    if (a.dtype == 2) return a.d == 128 ? launch_fwd_t<bf16_tag, 128>(a, st) : launch_fwd_t<bf16_tag, 64>(a, st);
-    return a.d == 128 ? launch_fwd_t<f16_tag, 128>(a, st) : launch_fwd_t<f16_tag, 64>(a, st);
+    if (a.dtype == 2) return a.d == 128 ? launch_fwd_kb<bf16_tag, 128>(a, st) : launch_fwd_kb<bf16_tag, 64>(a, st);
+    return a.d == 128 ? launch_fwd_kb<f16_tag, 128>(a, st) : launch_fwd_kb<f16_tag, 64>(a, st);
 }
 
 }  // namespace fa
