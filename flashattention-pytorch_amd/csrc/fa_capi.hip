@@ -192,12 +192,12 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
                 int dtype, int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
                 void* workspace, size_t workspace_bytes, void* stream) {
     (void)br; (void)bc; (void)stages;
-    if (fp8) {
+    // fp8 is a permission to use the e4m3 Q/K path, honoured where that kernel exists (16-bit tensors, d = 128,
+    // positive scale); every other shape takes the regular, more accurate path (as the reference quietly skips its
+    // rotation for non-power-of-two d, src/fa3/torch/impl.py:60-61).
+    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC) {
         int rc = check_common("fa3_forward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
-        if (!fa::fwd_fp8_supported(dtype, d))
-            return fail(FA_ERR_UNSUPPORTED, "fa3_forward: fp8=True needs f16/bf16 tensors and head_dim 64 or 128 (got dtype %d, d=%lld)",
-                        dtype, (long long)d);
         if (bh == 0 || n == 0) return FA_OK;
         if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_forward: null tensor pointer");
         const size_t need = fa3_forward_workspace_bytes(bh, n, d, dtype, 1);
@@ -215,9 +215,34 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
                  void* dq, void* dk, void* dv, int64_t bh, int64_t n, int64_t d, int dtype, int causal,
                  double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8, void* workspace,
                  size_t workspace_bytes, void* stream) {
-    (void)br; (void)bc; (void)stages; (void)fp8;  // straight-through: gradient of the un-quantised function
+    (void)br; (void)bc; (void)stages;
+    // fp8: differentiate the function the forward evaluated, i.e. attention of the e4m3-round-tripped Q and K
+    // (the reference's fa3_backward does the same, csrc/fa3/fa3_bwd.cu:134-146); the gradients are returned for
+    // q, k themselves (straight-through over the rounding).  o and lse then match the recomputed probabilities.
+    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC &&
+        bh > 0 && n > 0) {
+        int rc = check_common("fa3_backward", bh, n, d, dtype, softmax_scale);
+        if (rc != FA_OK) return rc;
+        if (!q || !k) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_backward: null tensor pointer");
+        const size_t base_need = fa_backward_workspace_bytes(bh, n, d, dtype);
+        const size_t need = fa3_backward_workspace_bytes(bh, n, d, dtype, 1);
+        if (!workspace || workspace_bytes < need)
+            return fail(FA_ERR_WORKSPACE, "fa3_backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        char* qt = reinterpret_cast<char*>(workspace) + base_need;
+        char* kt = qt + (size_t)bh * n * d * 2;
+        hipError_t e = fa::launch_fp8_roundtrip(q, k, qt, kt, bh, n, dtype, reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+        return backward_impl("fa3_backward", qt, kt, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
+                             workspace, base_need, stream);
+    }
     return backward_impl("fa3_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
                          workspace, workspace_bytes, stream);
+}
+
+size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
+    size_t need = fa_backward_workspace_bytes(bh, n, d, dtype);
+    if (fp8 && bh > 0 && n > 0 && d > 0 && fa::fwd_fp8_supported(dtype, d)) need += 2 * (size_t)bh * n * d * 2 + 256;
+    return need;
 }
 
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype) {
@@ -229,8 +254,7 @@ size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype) 
 }
 
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
-    if (!fp8 || bh <= 0 || n <= 0 || d <= 0) return 0;
-    (void)dtype;
+    if (!fp8 || bh <= 0 || n <= 0 || d <= 0 || !fa::fwd_fp8_supported(dtype, d)) return 0;
     return fa::fwd_fp8_workspace_bytes(bh, n, d);
 }
 

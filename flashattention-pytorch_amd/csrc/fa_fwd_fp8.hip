@@ -1,8 +1,288 @@
-// FA3-style fp8 forward — placeholder translation unit until the e4m3 kernel lands: reports "unsupported" so
-// fa3_forward(fp8=True) fails loudly (FA_ERR_UNSUPPORTED) instead of silently running the 16-bit path.
+// FA3-style fp8 forward for gfx950: Q and K quantised to OCP e4m3 with one scale per (b,h, 64-row block),
+// S = Q K^T on v_mfma_f32_32x32x16_fp8_fp8, softmax / P / V / O exactly as the 16-bit forward (P and V stay 16 bit,
+// fp32 accumulation).  head_dim 128, f16 / bf16 tensors.
+//
+// What it replaces: the fp8 branch of csrc/fa3/fa3_fwd.cu:196-208 (= src/fa3/torch/impl.py:118-133): per-block absmax
+// scales (block_absmax_scale, :70-85, eps 1e-6) and a quantise step.  The reference's quantise is an fp16 round trip
+// that models no 8-bit rounding, and its "Hadamard" rotation is not orthogonal; this implements the
+// intent — real e4m3 with block scales, no rotation — and is held to the reference's fp8 bar (1e-1,
+// tests/test_correctness_fa3.py:31-32) against the oracle's e4m3 model (oracle.fp8_attention) and the exact result.
+//
+// Two launches: fp8_quant_kernel (q and k -> e4m3 bytes + scales in the caller's workspace), fwd_fp8_kernel.
+// The e4m3 K tile is 64 keys x 128 BYTES: byte-for-byte the geometry of a 16-bit d=64 tile, so it reuses that LDS
+// image and LDS-DMA path (TileSwz<64>, dma_stage_tile<64,...>).  Each lane reads 16 bytes of a K row per step and feeds
+// two MFMAs (low / high 8 bytes); the Q fragment in registers uses the same byte order, so the k index matches.
+#include "fa_common.h"
 #include "fa_kernels.h"
+
 namespace fa {
-bool fwd_fp8_supported(int, int64_t) { return false; }
-hipError_t launch_fwd_fp8(const FwdArgs&, void*, hipStream_t) { return hipErrorNotSupported; }
-size_t fwd_fp8_workspace_bytes(int64_t, int64_t, int64_t) { return 0; }
+
+constexpr float kE4M3Max = 448.f;
+
+// one workgroup = one 64-row block of one (b,h) of one tensor (blockIdx.z: 0 = q, 1 = k)
+// OUT16 = false: write e4m3 bytes + scales (forward).  OUT16 = true: write the DEQUANTISED values back as 16-bit
+// tensors (backward: the gradient is taken of the function the forward actually evaluated, i.e. with the
+// quantised Q and K, which is also what the reference's fa3_backward does, csrc/fa3/fa3_bwd.cu:134-146).
+template <typename Tag, int D, bool OUT16>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                        uint8_t* __restrict__ q8, uint8_t* __restrict__ k8,
+                                                        float* __restrict__ sq, float* __restrict__ sk, int n, int nb) {
+    constexpr int CPR = D / 8, PER = (64 * CPR) / 256;  // 16-byte chunks per thread
+    __shared__ float red[4];
+    const uint16_t* src = blockIdx.z == 0 ? q : k;
+    uint8_t* dst = blockIdx.z == 0 ? q8 : k8;
+    float* sc = blockIdx.z == 0 ? sq : sk;
+    const int bh = blockIdx.y, blk = blockIdx.x, row0 = blk * 64;
+    const size_t base = (size_t)bh * n * D;
+    u32x4 x[PER];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i, row = row0 + c / CPR, ch = c % CPR;
+        x[i] = u32x4{0u, 0u, 0u, 0u};
+        if (row < n) x[i] = *reinterpret_cast<const u32x4*>(src + base + (size_t)row * D + 8 * ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(unpack_lo<Tag>(x[i][j])), fabsf(unpack_hi<Tag>(x[i][j]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    amax = fmaxf(amax, 1e-6f);                       // eps of block_absmax_scale
+    const float inv = kE4M3Max / amax;
+    const float scl = amax / kE4M3Max;
+    if (!OUT16 && threadIdx.x == 0) sc[(size_t)bh * nb + blk] = scl;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i, row = row0 + c / CPR, ch = c % CPR;
+        if (row >= n) continue;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][0]) * inv, unpack_hi<Tag>(x[i][0]) * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][1]) * inv, unpack_hi<Tag>(x[i][1]) * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][2]) * inv, unpack_hi<Tag>(x[i][2]) * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][3]) * inv, unpack_hi<Tag>(x[i][3]) * inv, w1, true);
+        if (!OUT16) {
+            u32x2 o2 = {(unsigned)w0, (unsigned)w1};
+            *reinterpret_cast<u32x2*>(dst + base + (size_t)row * D + 8 * ch) = o2;
+        } else {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            u32x4 o4;
+            const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+            const f32x2_t a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+            o4[0] = pack2_rn<Tag>(a0[0] * scl, a0[1] * scl);
+            o4[1] = pack2_rn<Tag>(a1[0] * scl, a1[1] * scl);
+            o4[2] = pack2_rn<Tag>(a2[0] * scl, a2[1] * scl);
+            o4[3] = pack2_rn<Tag>(a3[0] * scl, a3[1] * scl);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + base + (size_t)row * D + 8 * ch) = o4;
+        }
+    }
+}
+
+template <typename Tag, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
+                                                         const float* __restrict__ sq, const float* __restrict__ sk,
+                                                         const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                         float* __restrict__ lse, int n, int nqt, int nb, float c_log2) {
+    constexpr int D = 128, BM = 256, BN = 64, NM = D / 32, NDV = D / 32;
+    constexpr int K_BYTES = BN * D, V_BYTES = BN * D * 2, BUF = K_BYTES + V_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K8 tile | V tile]
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+
+    // ---- Q fragments: 16 e4m3 bytes per 32-wide d block: Q8[qrow][32 m + 16 h .. +15]
+    const buf_rsrc_t q_rs = make_rsrc(q8 + base, (unsigned)n * D);
+    u32x4 qf[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) qf[m] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qrow * D + 32 * m + 16 * h, 0, 0);
+    const int qblk = min((q0 + 32 * w) / 64, nb - 1);
+    const float fq = sq[(size_t)bh * nb + qblk] * c_log2;   // q-block scale folded with softmax_scale * log2(e)
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+
+    const buf_rsrc_t k_rs = make_rsrc(k8 + base, (unsigned)n * D);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const int voff_k = dma_lane_voff<64>(lane, w);    // 128-byte rows: the geometry of a 16-bit d = 64 tile
+    const int voff_v = dma_lane_voff<D>(lane, w);
+    auto stage = [&](int buf, int k0) {
+        char* b_ = smem + buf * BUF;
+        dma_stage_tile<64, BN, 8>(k_rs, b_, k0, voff_k, w);
+        dma_stage_tile<D, BN, 8>(v_rs, b_ + K_BYTES, k0, voff_v, w);
+    };
+
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units of the scaled score
+
+    stage(0, 0);
+    __syncthreads();
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+    const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
+
+    for (int t = 0; t < ntiles_w; ++t) {
+        const int k0 = t * BN, cur = t & 1;
+        if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);
+        const char* Kt = smem + cur * BUF;
+        const char* Vt = Kt + K_BYTES;
+        const float f = fq * sk[(size_t)bh * nb + t];   // one K scale per 64-key tile
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 2 * m + h));
+                const long a_lo = ((long)a[1] << 32) | a[0], a_hi = ((long)a[3] << 32) | a[2];
+                const long b_lo = ((long)qf[m][1] << 32) | qf[m][0], b_hi = ((long)qf[m][3] << 32) | qf[m][2];
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_lo, b_lo, sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_hi, b_hi, sacc[kb], 0, 0, 0);
+            }
+        }
+        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+        const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float s = ((i & 3) + 8 * (i >> 2) > thr) ? -INFINITY : sacc[kb][i] * f;
+                sacc[kb][i] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, wave_half_swap(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(sacc[kb][i] - m_use);
+                sacc[kb][i] = p;
+                rs += p;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
+                const s16x8 pb = *reinterpret_cast<s16x8*>(&pk);
+                const int key_a = 32 * kb + 16 * s + 4 * h + tq;
+#pragma unroll
+                for (int dvb = 0; dvb < NDV; ++dvb) {
+                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+                    const s16x8 a = cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
+                                         lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
+                    oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+                }
+            }
+        __syncthreads();
+    }
+    for (int t = ntiles_w; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + wave_half_swap(l_run);
+    if (qrow < n) {
+        const float inv = 1.f / l_tot;
+        uint16_t* orow = o + base + (size_t)qrow * D;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
+                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * g + 4 * h) = pk;
+            }
+        if (h == 0) lse[(size_t)bh * n + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+bool fwd_fp8_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
+
+// workspace: [q8: BH*N*D bytes][k8: BH*N*D bytes][sq: BH*nb floats][sk: BH*nb floats], nb = ceil(N/64)
+size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
+    const size_t nb = (size_t)((n + 63) / 64);
+    size_t bytes = 2 * (size_t)bh * n * d;
+    bytes = (bytes + 255) & ~(size_t)255;
+    return bytes + 2 * sizeof(float) * (size_t)bh * nb + 256;
+}
+
+template <typename Tag>
+static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
+    constexpr int D = 128;
+    const int nb = (int)((a.n + 63) / 64);
+    const size_t nbytes = (size_t)a.bh * a.n * D;
+    uint8_t* q8 = reinterpret_cast<uint8_t*>(ws);
+    uint8_t* k8 = q8 + nbytes;
+    float* sq = reinterpret_cast<float*>(q8 + ((2 * nbytes + 255) & ~(size_t)255));
+    float* sk = sq + (size_t)a.bh * nb;
+    {
+        ProfScope ps(K_FP8_QUANT, st);
+        hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
+                           (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nqt = (int)((a.n + 255) / 256);
+    const size_t smem = 2 * (64 * D + 64 * D * 2);
+    const float c = a.scale * 1.4426950408889634f;
+    dim3 grid((unsigned)(nqt * a.bh));
+    ProfScope ps(K_FWD_FP8, st);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)q8, (const uint8_t*)k8, (const float*)sq,
+                           (const float*)sk, (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, c);
+        return hipGetLastError();
+    };
+    return a.causal ? launch(fwd_fp8_kernel<Tag, true>) : launch(fwd_fp8_kernel<Tag, false>);
+}
+
+// q, k -> their e4m3 round trip (quantise with block scales, dequantise) as 16-bit tensors qt, kt
+hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
+                                hipStream_t st) {
+    const int nb = (int)((n + 63) / 64);
+    ProfScope ps(K_FP8_QUANT, st);
+    if (dtype == 2)
+        hipLaunchKernelGGL((fp8_quant_kernel<bf16_tag, 128, true>), dim3(nb, (unsigned)bh, 2), dim3(256), 0, st,
+                           (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt, (uint8_t*)kt, (float*)nullptr,
+                           (float*)nullptr, (int)n, nb);
+    else
+        hipLaunchKernelGGL((fp8_quant_kernel<f16_tag, 128, true>), dim3(nb, (unsigned)bh, 2), dim3(256), 0, st,
+                           (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt, (uint8_t*)kt, (float*)nullptr,
+                           (float*)nullptr, (int)n, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st) {
+    return a.dtype == 2 ? launch_fp8_t<bf16_tag>(a, workspace, st) : launch_fp8_t<f16_tag>(a, workspace, st);
+}
+
 }  // namespace fa

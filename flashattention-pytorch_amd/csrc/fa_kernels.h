@@ -59,5 +59,7 @@ hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* 
 bool fwd_fp8_supported(int dtype, int64_t d);
 hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st);
 size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
+hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
+                                hipStream_t st);
 
 }  // namespace fa

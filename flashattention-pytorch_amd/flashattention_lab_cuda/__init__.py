@@ -30,7 +30,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 EXPORTED_C_SYMBOLS = (
     "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
-    "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa_last_error", "fa_version",
+    "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
     "fa_set_kernel_mode", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
 )
 
@@ -59,6 +59,8 @@ def _load_library() -> ctypes.CDLL:
     lib.fa_backward_workspace_bytes.restype = sz
     lib.fa3_forward_workspace_bytes.argtypes = [i64, i64, i64, ci, ci]
     lib.fa3_forward_workspace_bytes.restype = sz
+    lib.fa3_backward_workspace_bytes.argtypes = [i64, i64, i64, ci, ci]
+    lib.fa3_backward_workspace_bytes.restype = sz
     lib.fa_last_error.restype = ctypes.c_char_p
     lib.fa_version.restype = ctypes.c_char_p
     lib.fa_set_kernel_mode.argtypes = [ci]
@@ -156,7 +158,10 @@ def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, ext
     lse = lse.contiguous()
     with torch.cuda.device(q.device):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        nbytes = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
+        if extra is not None:
+            nbytes = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1]))))
+        else:
+            nbytes = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, n, d, code, int(bool(causal)),

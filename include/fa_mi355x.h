@@ -78,10 +78,11 @@ int fa2_backward(const void* q, const void* k, const void* v, const void* o, con
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* --- FlashAttention-3 (replaces csrc/fa3/fa3_fwd.cu:172, csrc/fa3/fa3_bwd.cu:104).
- * fp8 != 0: Q and K are quantised to OCP e4m3 with one scale per (bh, 64-row block) and QK^T runs
- * on the fp8 MFMA; V, P and all accumulation stay 16/32-bit.  Needs dtype f16/bf16 and d in {64,128};
- * the forward then also needs a workspace (fa3_forward_workspace_bytes). The backward differentiates
- * the un-quantised function (straight-through), as the reference's tests require (tolerance 1e-1). */
+ * fp8 != 0: where the e4m3 kernel exists (f16/bf16 tensors, d = 128) Q and K are quantised to OCP e4m3 with one
+ * scale per (bh, 64-row block) and QK^T runs on the fp8 MFMA; V, P and all accumulation stay 16/32-bit, and the
+ * forward needs a workspace (fa3_forward_workspace_bytes, 0 when the kernel does not apply).  Other shapes take the
+ * regular 16/32-bit path.  The fp8 backward differentiates the function the forward evaluated (attention of the
+ * e4m3-round-tripped Q, K; cf. csrc/fa3/fa3_bwd.cu:134-146) and needs fa3_backward_workspace_bytes. */
 int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse,
                 int64_t bh, int64_t n, int64_t d, int dtype,
                 int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
@@ -96,6 +97,7 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
 /* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype);
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
+size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
 const char* fa_last_error(void);
 const char* fa_version(void);
 int fa_set_kernel_mode(int mode);      /* FA_MODE_*; returns the previous mode */

@@ -254,7 +254,8 @@ def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k):
     rk = torch.repeat_interleave(sk, block_k, dim=1)[:, :n]
     qd = qq * rq[..., None]
     kd = kq * rk[..., None]
-    return exact_attention(qd.to(q.dtype).float(), kd.to(k.dtype).float(), v.float(), causal, softmax_scale)
+    o, lse = exact_attention(qd, kd, v.float(), causal, softmax_scale)
+    return o.to(q.dtype), lse
 
 
 # --------------------------------------------------------------------------- FLOP accounting
