@@ -42,23 +42,19 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     const int kw0 = key0 + 32 * w;        // first key of this wave
     const int key = kw0 + r;              // this lane's key
 
-    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
-    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
-    const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
-    const buf_rsrc_t l_rs = make_rsrc(nlse + rbase, (unsigned)n * 4);
-    const buf_rsrc_t d_rs = make_rsrc(ndelta + rbase, (unsigned)n * 4);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * D * 2);
+    const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * D * 2);
+    const rsrc_s_t l_rs = make_rsrc_s(nlse + rbase, (unsigned)n * 4);
+    const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
     const int dma_voff = dma_lane_voff<D>(lane, w);
 
     auto stage = [&](int buf, int qs) {
         dma_stage_tile<D, BQ, 8>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w);
         dma_stage_tile<D, BQ, 8>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w);
         // row constants: 64 floats each, one 4-byte LDS-DMA per lane (rows >= n read as 0: harmless, their dO is 0)
-        if (w == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(Ls + buf * 128), 4,
-                                                     lane * 4, qs * 4, 0, 0);
-        if (w == 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (__attribute__((address_space(3))) void*)(Ls + buf * 128 + 64), 4,
-                                                     lane * 4, qs * 4, 0, 0);
+        if (w == 0) dma4_issue(l_rs, lds_addr_of(Ls + buf * 128), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
+        if (w == 1) dma4_issue(d_rs, lds_addr_of(Ls + buf * 128 + 64), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
     };
 
     // ---- prologue: K tile by LDS-DMA, V fragments to registers, first Q/dO tile
@@ -78,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     // first tile this wave computes: earlier tiles hold only queries before the wave's first key (causal)
     const int it_first = CAUSAL ? (kw0 / BQ) - (qs_first / BQ) : 0;
     stage(0, qs_first);
+    dma_wait_all();
     __syncthreads();
 
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
@@ -85,6 +82,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     // feed-only iterations (see fa_fwd_mfma.hip: two loops instead of a conditional accumulate)
     for (int it = 0; it < min(it_first, ntile); ++it) {
         if (it + 1 < ntile) stage((it & 1) ^ 1, qs_first + (it + 1) * BQ);
+        dma_wait_all();
         __syncthreads();
     }
     for (int it = it_first; it < ntile; ++it) {
@@ -173,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                 if (D > 64) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)), then the barrier
+        dma_wait_all();   // this wave's share of the next tile has landed
+        __syncthreads();
     }
 
     // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     const int ntiles = (kend + BN - 1) / BN;
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
-    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w);
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
         for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
 
     stage(0, 0);
+    dma_wait_all();
     __syncthreads();
 
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
@@ -128,11 +129,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
                     }
                 }
         }
-        __syncthreads();  // also drains this wave's LDS-DMA (vmcnt(0)) before the barrier
+        dma_wait_all();
+        __syncthreads();
     }
     // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
     for (int t = ntiles_w; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        dma_wait_all();
         __syncthreads();
     }
 

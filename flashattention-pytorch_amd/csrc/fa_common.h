@@ -136,16 +136,46 @@ __device__ __forceinline__ int dma_lane_voff(int lane, int w) {
     const int ch = (TileSwz<D>::off(row, slot) - 2 * D * row) >> 4;
     return rl * 2 * D + 16 * ch;
 }
+// The DMA itself is issued from inline asm, so hipcc does not see it: with the builtin form hipcc treats every later
+// ds_read_b64_tr_b16 as possibly aliasing the pending LDS write and parks the wave on s_waitcnt vmcnt(0) in the
+// middle of the tile (the DMA's whole latency exposed).  The price: nothing waits for the data unless we do —
+// dma_wait_all() (s_waitcnt vmcnt(0)) must precede the barrier after which other waves read the tile.
+// M0 carries the LDS base for the instruction; it is saved/restored around it (hipcc reserves M0).
+typedef u32x4 rsrc_s_t;   // buffer descriptor held in SGPRs (every word wave-uniform)
+__device__ __forceinline__ rsrc_s_t make_rsrc_s(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    rsrc_s_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ void dma16_issue(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4_issue(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // stage rows [row0, row0 + ROWS) of the tensor behind `rsrc` (row stride 2*D bytes) into the LDS tile at `tile`
 template <int D, int ROWS, int NW>
-__device__ __forceinline__ void dma_stage_tile(buf_rsrc_t rsrc, char* tile, int row0, int voff, int w) {
+__device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int row0, int voff, int w) {
     constexpr int RPP = 512 / D, PIECES = ROWS / RPP, PER_WAVE = PIECES / NW;
     static_assert(PIECES % NW == 0 && (RPP * NW) % 16 == 0, "tile does not split evenly over the waves");
+    const unsigned t0 = lds_addr_of(tile);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
         const int pc = w + NW * j;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + pc * 1024), 16, voff,
-                                                 (row0 + RPP * pc) * 2 * D, 0, 0);
+        dma16_issue(rsrc, t0 + pc * 1024, voff, __builtin_amdgcn_readfirstlane((row0 + RPP * pc) * 2 * D));
     }
 }
 

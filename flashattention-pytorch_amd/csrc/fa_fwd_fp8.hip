@@ -109,8 +109,8 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
     const int kend = CAUSAL ? min(n, q0 + BM) : n;
     const int ntiles = (kend + BN - 1) / BN;
 
-    const buf_rsrc_t k_rs = make_rsrc(k8 + base, (unsigned)n * D);
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k8 + base, (unsigned)n * D);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
     const int voff_k = dma_lane_voff<64>(lane, w);    // 128-byte rows: the geometry of a 16-bit d = 64 tile
     const int voff_v = dma_lane_voff<D>(lane, w);
     auto stage = [&](int buf, int k0) {
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
     float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units of the scaled score
 
     stage(0, 0);
+    dma_wait_all();
     __syncthreads();
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
@@ -200,10 +201,12 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
                     oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
                 }
             }
+        dma_wait_all();
         __syncthreads();
     }
     for (int t = ntiles_w; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        dma_wait_all();
         __syncthreads();
     }
 

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     const int ntiles = (kend + BN - 1) / BN;
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
-    const buf_rsrc_t k_rs = make_rsrc(k + base, (unsigned)n * D * 2);
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w);
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     float l_run = 0.f;        // this half-wave's share of the running sum
 
     stage(0, 0);
+    dma_wait_all();
     __syncthreads();
 
     // lane-constant pieces of the transposed V read address
@@ -161,11 +162,13 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                 }
             }
         }
-        __syncthreads();  // also drains this wave's LDS-DMA (vmcnt(0)) before the barrier
+        dma_wait_all();   // this wave's share of the next tile has landed ...
+        __syncthreads();  // ... and so has everyone else's
     }
     // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
     for (int t = ntiles_w; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        dma_wait_all();
         __syncthreads();
     }
 
@@ -189,6 +192,184 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 
 bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
 
+// ------------------------------------------------------------------------------------------------
+// Staggered variant (FA_FWD_STAG=1; NOT the default: measured 2.58 ms vs 2.1-2.2 ms for the lock-step kernel at
+// B8 H32 N4096 d128, profiles/r01_tile_sweep.md).  The two waves that share a SIMD run the same program; with one barrier per tile they stay in
+// lock step, so their MFMA phases collide and their softmax (VALU) phases collide, and the tile time is the SUM of
+// the two.  Here every tile is split in two halves separated by barriers,
+//     M_t = [ O^T += V^T P^T (tile t-1) ; S^T = K Q^T (tile t) ]      matrix pipe
+//     V_t = [ online softmax of tile t, O rescale, pack P ]           vector pipe
+// and waves 4..7 run half a tile behind waves 0..3, so at any time one wave of a SIMD is in M and the other in V.
+// LDS-DMA is issued at even global half-steps g = 2u: K(u+1) and V(u); K and V are each double buffered (V lags K by
+// one tile), which keeps every buffer alive exactly as long as the later half of the workgroup reads it.
+template <typename Tag, int D, bool CAUSAL, int KB>
+__global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                               float* __restrict__ lse, int n, int nqt, float c_log2,
+                                                               float scale) {
+    constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
+    constexpr int TILE_BYTES = BN * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    char* Kbuf = smem;
+    char* Vbuf = smem + 2 * TILE_BYTES;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+    const int stag = w >> 2;   // waves 4..7 (the second wave of every SIMD) run one half-step behind
+
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    s16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int T = (kend + BN - 1) / BN;                                               // tiles of the workgroup
+    const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31) / BN + 1) : T;                  // tiles this wave computes
+
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w);
+    auto issue = [&](int u) {   // start of global half-step 2u
+        if (u + 1 < T) dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 1) & 1) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
+        if (u < T) dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (u & 1) * TILE_BYTES, u * BN, dma_voff, w);
+    };
+
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sacc[KB];
+    u32x4 pp[KB][2];
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+    auto do_S = [&](int t) {
+        const char* Kt = Kbuf + (t & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
+                sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
+            }
+        }
+    };
+    auto do_softmax = [&](int t) {
+        const int k0 = t * BN;
+        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+        if (need_mask) {
+            const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int thr = lim - (k0 + 32 * kb + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((i & 3) + 8 * (i >> 2) > thr) sacc[kb][i] = -INFINITY;
+            }
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
+        mx = fmaxf(mx, wave_half_swap(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
+        const float mc = m_use * c_log2;
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
+                sacc[kb][i] = p;
+                rs += p;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
+    };
+    auto do_PV = [&](int t) {
+        const char* Vt = Vbuf + (t & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[kb][s]);
+                const int key_a = 32 * kb + 16 * s + 4 * h + tq;
+#pragma unroll
+                for (int dvb = 0; dvb < NDV; ++dvb) {
+                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+                    const s16x8 a = cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
+                                         lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
+                    oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+                }
+            }
+    };
+
+    // K(0), then global half-steps g = 0 .. 2T+1, one barrier after each; a wave's local step is g - stag
+    // A DMA issued at an even half-step 2u is first read in half-step 2u+2: it has to have landed by the barrier that
+    // ends the ODD half-step 2u+1, so that is where each wave waits for its own share (never in between).
+    auto end_half = [&](int gg) { if (gg & 1) dma_wait_all(); __syncthreads(); };
+    dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w);
+    dma_wait_all();
+    __syncthreads();
+    int g = 0;
+    if (stag) { issue(0); end_half(0); g = 1; }               // second half idles through half-step 0
+    if (!(g & 1)) issue(g >> 1);
+    do_S(0);                                                  // M_0
+    end_half(g); ++g;
+    for (int t = 0; t < Tw; ++t) {
+        if (!(g & 1)) issue(g >> 1);
+        do_softmax(t);                                        // V_t
+        end_half(g); ++g;
+        if (!(g & 1)) issue(g >> 1);
+        do_PV(t);                                             // M_{t+1}
+        if (t + 1 < Tw) do_S(t + 1);
+        end_half(g); ++g;
+    }
+    for (; g < 2 * T + 2; ++g) {                              // feed-only half-steps (causal tail, idle half)
+        if (!(g & 1)) issue(g >> 1);
+        end_half(g);
+    }
+
+    const float l_tot = l_run + wave_half_swap(l_run);
+    if (qrow < n) {
+        const float inv = 1.f / l_tot;
+        uint16_t* orow = o + base + (size_t)qrow * D;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
+                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
+            }
+        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+    }
+}
+
 // K/V tile size in 32-key blocks: 4 (128 keys) is the measured winner (profiles/r01_tile_sweep.md);
 // FA_FWD_KB=1|2|4 overrides it for the sweep (1 only at d = 128).
 static int fwd_kb_override() {
@@ -211,15 +392,22 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
         return hipGetLastError();
     };
+    static const int stag = [] { const char* e = getenv("FA_FWD_STAG"); return e ? atoi(e) : 0; }();
+    if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB>) : launch(fwd_mfma_kernel<Tag, D, false, KB>);
 }
 
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
+    static const int stag = [] { const char* e = getenv("FA_FWD_STAG"); return e ? atoi(e) : 0; }();
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
-    return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key, LDS 128 KiB at d = 128
+    if (kb == 4) return launch_fwd_t<Tag, D, 4>(a, st);
+    // defaults: the staggered kernel keeps S and the packed P live across its half-step barriers, so at d = 128 it
+    // takes 64-key tiles (234 registers; 128-key tiles spill); the lock-step kernel prefers 128-key tiles
+    if (stag && D == 128) return launch_fwd_t<Tag, D, 2>(a, st);
+    return launch_fwd_t<Tag, D, 4>(a, st);
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
