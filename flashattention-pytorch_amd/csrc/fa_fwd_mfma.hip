@@ -124,24 +124,21 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
             const float mc = m_use * c_log2;
             m_run = m_new;
+            // O rescale first (it only needs alpha), then per 32-key block: exp2 -> pack -> issue that block's P.V MFMAs.
+            // The MFMAs execute asynchronously, so the next block's exp2 / sum / pack (VALU) runs underneath them.
+#pragma unroll
+            for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
             float rs = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
                     sacc[kb][i] = p;
                     rs += p;
                 }
-            l_run = l_run * alpha + rs;
-#pragma unroll
-            for (int t2 = 0; t2 < NDV; ++t2)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
-
-            // ---- O^T += V^T P^T
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     u32x4 pk;
@@ -161,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                     }
                 }
             }
+            l_run = l_run * alpha + rs;
         }
         dma_wait_all();   // this wave's share of the next tile has landed ...
         __syncthreads();  // ... and so has everyone else's
@@ -370,6 +368,208 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (FA_FWD_PIPE=1): S^T of tile t+1 (matrix pipe) is issued in the same basic block as the
+// online softmax of tile t (vector pipe), so one wave's instruction stream alternates MFMA and VALU work instead of
+// running them back to back; P.V of tile t follows.  K is prefetched two tiles ahead, V one (K and V each double
+// buffered), one barrier per tile.
+template <typename Tag, int D, bool CAUSAL, int KB>
+__global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                               float* __restrict__ lse, int n, int nqt, float c_log2,
+                                                               float scale) {
+    constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
+    constexpr int TILE_BYTES = BN * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    char* Kbuf = smem;
+    char* Vbuf = smem + 2 * TILE_BYTES;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    s16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int T = (kend + BN - 1) / BN;
+    const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31) / BN + 1) : T;
+
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w);
+    auto load_k = [&](int t) { if (t < T) dma_stage_tile<D, BN, 8>(k_rs, Kbuf + (t & 1) * TILE_BYTES, t * BN, dma_voff, w); };
+    auto load_v = [&](int t) { if (t < T) dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (t & 1) * TILE_BYTES, t * BN, dma_voff, w); };
+
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+    auto do_S = [&](int t, f32x16 (&sacc)[KB]) {
+        const char* Kt = Kbuf + (t & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
+                sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
+            }
+        }
+    };
+    // softmax of tile t in place (sacc -> P), O rescale, packed P out
+    auto do_softmax = [&](int t, f32x16 (&sacc)[KB], u32x4 (&pp)[KB][2]) {
+        const int k0 = t * BN;
+        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+        const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if ((i & 3) + 8 * (i >> 2) > thr) sacc[kb][i] = -INFINITY;
+                mx = fmaxf(mx, sacc[kb][i]);
+            }
+        }
+        mx = fmaxf(mx, wave_half_swap(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
+        const float mc = m_use * c_log2;
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
+                sacc[kb][i] = p;
+                rs += p;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
+        }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+    };
+    auto do_PV = [&](int t, u32x4 (&pp)[KB][2]) {
+        const char* Vt = Vbuf + (t & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[kb][s]);
+                const int key_a = 32 * kb + 16 * s + 4 * h + tq;
+#pragma unroll
+                for (int dvb = 0; dvb < NDV; ++dvb) {
+                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+                    const s16x8 a = cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
+                                         lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
+                    oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+                }
+            }
+    };
+
+    // Scheduling directive for the region that holds S(t+1) and softmax(t): one MFMA, its K fragment read, then a
+    // slice of the softmax VALU work, repeated — an in-order wave only overlaps its own MFMA and VALU work when they
+    // alternate in program order (hipcc otherwise emits all 8*KB MFMAs first, then the softmax).
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < KB * NKS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x402, 16, 0);  // VALU + TRANS
+        }
+    };
+    load_k(0); load_k(1); load_v(0);
+    dma_wait_all();
+    __syncthreads();
+    f32x16 sa[KB], sb[KB];
+    u32x4 pp[KB][2];
+    do_S(0, sa);
+    // steady state: tiles come in pairs so that the two S buffers keep static names (no runtime-indexed registers)
+    int t = 0;
+    for (; t + 2 <= Tw - 1; t += 2) {
+        load_k(t + 2); load_v(t + 1);
+        do_S(t + 1, sb);            // matrix pipe ...
+        do_softmax(t, sa, pp);      // ... under the vector work of the previous tile
+        interleave();
+        do_PV(t, pp);
+        dma_wait_all();
+        __syncthreads();
+        load_k(t + 3); load_v(t + 2);
+        do_S(t + 2, sa);
+        do_softmax(t + 1, sb, pp);
+        interleave();
+        do_PV(t + 1, pp);
+        dma_wait_all();
+        __syncthreads();
+    }
+    // tail: one or two tiles left, `sa` holds S of tile t
+    if (t + 1 <= Tw - 1) {
+        load_k(t + 2); load_v(t + 1);
+        do_S(t + 1, sb);
+        do_softmax(t, sa, pp);
+        interleave();
+        do_PV(t, pp);
+        dma_wait_all();
+        __syncthreads();
+        load_k(t + 3); load_v(t + 2);
+        do_softmax(t + 1, sb, pp);
+        do_PV(t + 1, pp);
+        dma_wait_all();
+        __syncthreads();
+        t += 2;
+    } else {
+        load_k(t + 2); load_v(t + 1);
+        do_softmax(t, sa, pp);
+        do_PV(t, pp);
+        dma_wait_all();
+        __syncthreads();
+        t += 1;
+    }
+    for (; t < T; ++t) {   // causal: keep feeding the tiles the other waves still need
+        load_k(t + 2); load_v(t + 1);
+        dma_wait_all();
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + wave_half_swap(l_run);
+    if (qrow < n) {
+        const float inv = 1.f / l_tot;
+        uint16_t* orow = o + base + (size_t)qrow * D;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
+                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
+            }
+        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+    }
+}
+
 // K/V tile size in 32-key blocks: 4 (128 keys) is the measured winner (profiles/r01_tile_sweep.md);
 // FA_FWD_KB=1|2|4 overrides it for the sweep (1 only at d = 128).
 static int fwd_kb_override() {
@@ -393,6 +593,8 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         return hipGetLastError();
     };
     static const int stag = [] { const char* e = getenv("FA_FWD_STAG"); return e ? atoi(e) : 0; }();
+    static const int pipe = [] { const char* e = getenv("FA_FWD_PIPE"); return e ? atoi(e) : 0; }();
+    if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
     if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB>) : launch(fwd_mfma_kernel<Tag, D, false, KB>);
 }
