@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
+#include <cstdint>
 
 namespace {
 
@@ -66,11 +68,21 @@ bool bwd_atomic_variant() {
 }
 // the 16-bit MFMA kernels fold softmax_scale into the exp2 argument and need it finite and > 0
 bool scale_ok(double s) { return s > 1e-20 && s < 1e20; }
-bool use_mfma_fwd(int dtype, int64_t d, double s) {
-    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && fa::fwd_mfma_supported(dtype, d);
+// The 16-bit MFMA kernels read 16 bytes per lane and address each (b,h) slab with 32-bit byte offsets:
+// every tensor must be 16-byte aligned and N*d*2 must stay below 2^31.  Anything else takes the exact-f32 kernels.
+bool aligned16(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return true;
 }
-bool use_mfma_bwd(int dtype, int64_t d, double s) {
-    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && fa::bwd_mfma_supported(dtype, d);
+bool slab_ok(int64_t n, int64_t d) { return n * d * 2 < ((int64_t)1 << 31) - 65536; }
+bool use_mfma_fwd(int dtype, int64_t n, int64_t d, double s, std::initializer_list<const void*> ps) {
+    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && slab_ok(n, d) && aligned16(ps) &&
+           fa::fwd_mfma_supported(dtype, d);
+}
+bool use_mfma_bwd(int dtype, int64_t n, int64_t d, double s, std::initializer_list<const void*> ps) {
+    return g_mode.load() != FA_MODE_F32_GENERIC && scale_ok(s) && slab_ok(n, d) && aligned16(ps) &&
+           fa::bwd_mfma_supported(dtype, d);
 }
 
 int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
@@ -81,7 +93,7 @@ int forward_impl(const char* who, const void* q, const void* k, const void* v, v
     if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", who);
     fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)scale};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = use_mfma_fwd(dtype, d, scale) ? fa::launch_fwd_mfma(a, st) : fa::launch_fwd_generic(a, st);
+    hipError_t e = use_mfma_fwd(dtype, n, d, scale, {q, k, v, o}) ? fa::launch_fwd_mfma(a, st) : fa::launch_fwd_generic(a, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
     return FA_OK;
 }
@@ -100,7 +112,7 @@ int backward_impl(const char* who, const void* q, const void* k, const void* v, 
     fa::BwdArgs a{q, k, v, o, dout, lse, dq, dk, dv, bh, n, d, dtype, causal ? 1 : 0, (float)scale, ws, ws_bytes,
                    bwd_atomic_variant() ? 1 : 0};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = use_mfma_bwd(dtype, d, scale) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
+    hipError_t e = use_mfma_bwd(dtype, n, d, scale, {q, k, v, o, dout, dq, dk, dv, ws}) ? fa::launch_bwd_mfma(a, st) : fa::launch_bwd_generic(a, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: HIP error %d (%s)", who, (int)e, hipGetErrorString(e));
     return FA_OK;
 }
@@ -195,7 +207,8 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
     // fp8 is a permission to use the e4m3 Q/K path, honoured where that kernel exists (16-bit tensors, d = 128,
     // positive scale); every other shape takes the regular, more accurate path (as the reference quietly skips its
     // rotation for non-power-of-two d, src/fa3/torch/impl.py:60-61).
-    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC) {
+    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC &&
+        slab_ok(n, d) && aligned16({q, k, v, o, workspace})) {
         int rc = check_common("fa3_forward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
         if (bh == 0 || n == 0) return FA_OK;
@@ -220,7 +233,7 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
     // (the reference's fa3_backward does the same, csrc/fa3/fa3_bwd.cu:134-146); the gradients are returned for
     // q, k themselves (straight-through over the rounding).  o and lse then match the recomputed probabilities.
     if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC &&
-        bh > 0 && n > 0) {
+        slab_ok(n, d) && aligned16({q, k, workspace}) && bh > 0 && n > 0) {
         int rc = check_common("fa3_backward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
         if (!q || !k) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_backward: null tensor pointer");

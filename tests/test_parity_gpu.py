@@ -317,3 +317,21 @@ def test_fa3_fp8_config5_shape_runs(device):
     mo, mlse = orc.fp8_attention(q[:1, :].float(), k[:1].float(), v[:1].float(), False, d ** -0.5, 64, 64)
     torch.testing.assert_close(o[:1].cpu().float(), mo, rtol=2e-2, atol=2e-2)
     assert max_abs(lse[:1].cpu(), mlse) < 2e-2
+
+
+def test_misaligned_storage_offset_takes_the_scalar_path(device):
+    """A contiguous tensor whose storage offset is not a multiple of 16 bytes cannot use the 16-byte vector loads of
+    the MFMA kernels; the library must notice and still return the right answer."""
+    bh, n, d = 2, 70, 64
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=8)
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=device)
+        buf[1:].copy_(t.reshape(-1))
+        return buf[1:].view(t.shape)
+    qs, ks, vs = shifted(q), shifted(k), shifted(v)
+    assert qs.data_ptr() % 16 != 0 and qs.is_contiguous()
+    o, lse, dq, dk, dv = _run(2, qs, ks, vs, True, d ** -0.5, do=do.to(device))
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, True, d ** -0.5, math_dtype=torch.float64)
+    torch.testing.assert_close(o.cpu(), ro, rtol=5e-2, atol=5e-2)
+    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
+        torch.testing.assert_close(a.cpu(), b, rtol=5e-2, atol=5e-2)
