@@ -335,3 +335,30 @@ def test_misaligned_storage_offset_takes_the_scalar_path(device):
     torch.testing.assert_close(o.cpu(), ro, rtol=5e-2, atol=5e-2)
     for a, b in ((dq, rq), (dk, rk), (dv, rv)):
         torch.testing.assert_close(a.cpu(), b, rtol=5e-2, atol=5e-2)
+
+
+def test_forward_backward_capture_into_a_hip_graph(device):
+    """The launch path does no allocation, sync or memcpy of its own, so a caller can capture forward + backward into
+    a HIP graph and replay it (cdna guide §6 Guideline 9)."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = (t.to(device) for t in make_qkv(4, 300, 128, torch.bfloat16, seed=12))
+    ref_o, ref_lse = ext.forward(q, k, v, True, 0.1, 64, 128)
+    ref_g = ext.backward(q, k, v, ref_o, do, ref_lse, True, 0.1, 64, 128)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):   # warm-up on the side stream, as torch's capture protocol asks
+        ext.forward(q, k, v, True, 0.1, 64, 128)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o, lse = ext.forward(q, k, v, True, 0.1, 64, 128)
+        dq, dk, dv = ext.backward(q, k, v, o, do, lse, True, 0.1, 64, 128)
+    for _ in range(3):
+        o.zero_(); dq.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o, ref_o) and torch.equal(lse, ref_lse)
+    for a, b in zip((dq, dk, dv), ref_g):
+        assert torch.equal(a, b)
