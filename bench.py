@@ -135,6 +135,7 @@ def main():
         o = step()
     torch.cuda.synchronize()
     barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

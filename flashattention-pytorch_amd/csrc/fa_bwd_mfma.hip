@@ -374,7 +374,7 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     // dK/dV pass of the split backward: the 8-wave kernel (two waves per SIMD) where its register budget holds
     // is the default; FA_DKDV=w4 selects the 4-wave / 512-register kernel below (tile sweep evidence).
-    static const int dkdv_env = [] { const char* e = getenv("FA_DKDV"); return !e ? 0 : (!strcmp(e, "w8") ? 8 : (!strcmp(e, "w4") ? 4 : 0)); }();
+    const int dkdv_env = option(OPT_DKDV);
     if (!fused && dkdv_env != 4) {
         e = launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
         if (e != hipSuccess) return e;

@@ -37,6 +37,20 @@ hipEvent_t prof_get_event() {
     return e;
 }
 
+// ---- tuning knobs ---------------------------------------------------------------------------------
+const char* const kOptNames[fa::OPT_COUNT] = {"fwd_kb", "fwd_stag", "fwd_pipe", "dkdv"};
+const char* const kOptEnv[fa::OPT_COUNT] = {"FA_FWD_KB", "FA_FWD_STAG", "FA_FWD_PIPE", "FA_DKDV"};
+std::atomic<int> g_opts[fa::OPT_COUNT];
+std::once_flag g_opts_once;
+void init_opts() {
+    for (int i = 0; i < fa::OPT_COUNT; ++i) {
+        const char* e = getenv(kOptEnv[i]);
+        int v = 0;
+        if (e) v = (e[0] == 'w') ? atoi(e + 1) : atoi(e);   // FA_DKDV=w4 / w8 are accepted as 4 / 8
+        g_opts[i].store(v);
+    }
+}
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -120,6 +134,16 @@ int backward_impl(const char* who, const void* q, const void* k, const void* v, 
 }  // namespace
 
 namespace fa {
+int option(int id) {
+    std::call_once(g_opts_once, init_opts);
+    return g_opts[id].load(std::memory_order_relaxed);
+}
+int set_option(const char* name, int value) {
+    std::call_once(g_opts_once, init_opts);
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, kOptNames[i])) { g_opts[i].store(value); return 0; }
+    return -1;
+}
 void prof_begin(int id, hipStream_t st) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -269,6 +293,11 @@ size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype) 
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
     if (!fp8 || bh <= 0 || n <= 0 || d <= 0 || !fa::fwd_fp8_supported(dtype, d)) return 0;
     return fa::fwd_fp8_workspace_bytes(bh, n, d);
+}
+
+int fa_set_option(const char* name, int value) {
+    if (!name || fa::set_option(name, value) != 0) return fail(FA_ERR_INVALID_ARGUMENT, "fa_set_option: unknown option '%s'", name ? name : "(null)");
+    return FA_OK;
 }
 
 const char* fa_last_error(void) { return g_err; }

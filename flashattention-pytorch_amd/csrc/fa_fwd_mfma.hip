@@ -572,10 +572,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* _
 
 // K/V tile size in 32-key blocks: 4 (128 keys) is the measured winner (profiles/r01_tile_sweep.md);
 // FA_FWD_KB=1|2|4 overrides it for the sweep (1 only at d = 128).
-static int fwd_kb_override() {
-    static const int v = [] { const char* e = getenv("FA_FWD_KB"); return e ? atoi(e) : 0; }();
-    return v;
-}
+static int fwd_kb_override() { return option(OPT_FWD_KB); }
 
 template <typename Tag, int D, int KB>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
@@ -592,8 +589,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
         return hipGetLastError();
     };
-    static const int stag = [] { const char* e = getenv("FA_FWD_STAG"); return e ? atoi(e) : 0; }();
-    static const int pipe = [] { const char* e = getenv("FA_FWD_PIPE"); return e ? atoi(e) : 0; }();
+    const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
     if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
     if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB>) : launch(fwd_mfma_kernel<Tag, D, false, KB>);
@@ -602,7 +598,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
-    static const int stag = [] { const char* e = getenv("FA_FWD_STAG"); return e ? atoi(e) : 0; }();
+    const int stag = option(OPT_FWD_STAG);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
     if (kb == 4) return launch_fwd_t<Tag, D, 4>(a, st);

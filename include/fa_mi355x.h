@@ -101,6 +101,7 @@ size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype,
 const char* fa_last_error(void);
 const char* fa_version(void);
 int fa_set_kernel_mode(int mode);      /* FA_MODE_*; returns the previous mode */
+int fa_set_option(const char* name, int value); /* tuning knobs for sweeps: fwd_kb, fwd_stag, fwd_pipe, dkdv */
 int fa_device_is_gfx950(int device);   /* 1 if `device` reports gcnArchName gfx950, 0 otherwise, <0 on HIP error */
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figure).
  * fa_profile_enable(1) starts collecting (and clears old records), fa_profile_report waits for the events and
