@@ -15,14 +15,14 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, int KT>
 __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ nlse,
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dq,
                                                              int n, int nqt, float c_log2, float scale) {
-    constexpr int BM = 256, BN = 64, NKS = D / 16, NDB = D / 32, CPR = D / 8;
+    constexpr int BM = 256, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -81,9 +81,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
         const int k0 = t * BN;
         const int cur = t & 1;
         if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);  // nobody reads that buffer: all waves passed the last barrier
-        const char* Kt = smem + cur * 2 * TILE_BYTES;
-        const char* Vt = Kt + TILE_BYTES;
-        {
+#pragma unroll 1
+        for (int sub = 0; sub < KT; ++sub) {   // not unrolled: the body already sits at the register limit
+            const int k0s = k0 + 64 * sub;                       // first key of this 64-key sub-tile
+            const char* Kt = smem + cur * 2 * TILE_BYTES + sub * 64 * D * 2;
+            const char* Vt = Kt + TILE_BYTES;
             u32x4 dsb[2][2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
                     const s16x8 va = *reinterpret_cast<const s16x8*>(Vt + off);
                     pacc = mfma32<Tag>(va, of[ks], pacc);
                 }
-                const bool need_mask = (CAUSAL && (k0 + 32 * kb + 31 > q0 + 32 * w)) || (k0 + 32 * kb + 32 > n);
+                const bool need_mask = (CAUSAL && (k0s + 32 * kb + 31 > q0 + 32 * w)) || (k0s + 32 * kb + 32 > n);
                 // register i holds key k0 + 32 kb + 4 h + rc(i): one per-lane threshold, no branch
                 const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
-                const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+                const int thr = need_mask ? lim - (k0s + 32 * kb + 4 * h) : 64;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
@@ -153,11 +155,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     }
 }
 
-template <typename Tag, int D>
-static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+template <typename Tag, int D, int KT>
+static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     constexpr int BM = 256;
     const int nqt = (int)((a.n + BM - 1) / BM);
-    const size_t smem = 2 * 2 * 64 * D * 2;
+    const size_t smem = 2 * 2 * (64 * KT) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);
@@ -169,7 +171,14 @@ static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* 
                            a.scale);
         return hipGetLastError();
     };
-    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true>) : launch(bwd_dq_mfma_kernel<Tag, D, false>);
+    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT>);
+}
+
+// K/V tile of the dQ pass: 64 keys per barrier is the measured winner (2.98 vs 3.43 ms, profiles/r01_tile_sweep.md);
+// option dq_kt=2 selects two 64-key sub-tiles per barrier (sweep)
+template <typename Tag, int D>
+static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    return option(OPT_DQ_KT) == 2 ? launch_dq_kt<Tag, D, 2>(a, nlse, ndelta, st) : launch_dq_kt<Tag, D, 1>(a, nlse, ndelta, st);
 }
 
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {

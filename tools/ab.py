@@ -15,8 +15,9 @@ VARIANTS = [
     ("base", {}),
     ("dkdv 4 waves x 64 keys", {"dkdv": 4}),
     ("fwd_kb=2", {"fwd_kb": 2}),
+    ("dq 2x64-key sub-tiles per barrier", {"dq_kt": 2}),
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt"]
 
 
 def main():
