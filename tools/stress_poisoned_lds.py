@@ -1,3 +1,5 @@
+"""Stress check: run ragged shapes after filling every CU's LDS with NaN patterns (a kernel that reads LDS bytes it never
+wrote - e.g. padded rows the DMA range check should have zero-filled - then shows up as NaN or a wrong row)."""
 import sys, torch
 sys.path.insert(0, "flashattention-pytorch_amd"); sys.path.insert(0, ".")
 from oracle import attention_oracle as orc
