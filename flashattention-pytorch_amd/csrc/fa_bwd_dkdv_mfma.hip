@@ -148,8 +148,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        sp[s][j] = pack2<Tag>(unpack_lo<Tag>(pp[s][j]) * pacc[8 * s + 2 * j],
-                                              unpack_hi<Tag>(pp[s][j]) * pacc[8 * s + 2 * j + 1]);
+                        sp[s][j] = mul_pack<Tag>(pp[s][j], pacc[8 * s + 2 * j], pacc[8 * s + 2 * j + 1]);
             }
             if (D > 64) __builtin_amdgcn_sched_barrier(0);
             // ---- dV^T += dO^T P ,  dK^T += Q^T dS   (A operands: transposed reads of the dO / Q tiles)

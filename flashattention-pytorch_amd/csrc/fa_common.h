@@ -62,6 +62,19 @@ template <> __device__ __forceinline__ float unpack_hi<f16_tag>(uint32_t v) {
     return __half2float(__ushort_as_half((unsigned short)(v >> 16)));
 }
 
+// packed (p_lo * a, p_hi * b) where p is a packed 16-bit pair: dS = P * dP' with the 16-bit P that also feeds dV.
+template <typename Tag> __device__ __forceinline__ uint32_t mul_pack(uint32_t p, float a, float b);
+template <> __device__ __forceinline__ uint32_t mul_pack<bf16_tag>(uint32_t p, float a, float b) {
+    return pack2<bf16_tag>(unpack_lo<bf16_tag>(p) * a, unpack_hi<bf16_tag>(p) * b);
+}
+template <> __device__ __forceinline__ uint32_t mul_pack<f16_tag>(uint32_t p, float a, float b) {
+    // f16 has a packed multiply: round dP' to f16 (11 significant bits, more than bf16 keeps) and multiply in f16
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const uint32_t ab = pack2<f16_tag>(a, b);
+    const h2_t r = __builtin_bit_cast(h2_t, p) * __builtin_bit_cast(h2_t, ab);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 // ---- MFMA wrappers: 32x32x16, 16-bit inputs, f32 accumulate ----
 template <typename Tag> __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c);
 template <> __device__ __forceinline__ f32x16 mfma32<bf16_tag>(s16x8 a, s16x8 b, f32x16 c) {
