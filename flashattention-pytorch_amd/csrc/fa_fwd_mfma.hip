@@ -19,10 +19,11 @@
 #include "fa_common.h"
 #include "fa_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB>
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -66,7 +67,16 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
     float m_run = -INFINITY;  // running max of the raw scores (before softmax_scale) of this lane's query row
-    float l_run = 0.f;        // this half-wave's share of the running sum
+    float l_run = 0.f;        // this half-wave's share of the running sum (VALU row-sum variant)
+    // RS_MFMA: the row sum rides the matrix pipe instead — one extra MFMA per k-step with an all-ones A operand gives
+    // sum_key P[q][key] in every register of `lacc` (col = this lane's query, both lane halves included).  The vector
+    // pipe is the busier one here (MFMA-busy 43 %), and the sum then uses exactly the rounded P that feeds P.V.
+    f32x16 lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+    s16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (short)(sizeof(Tag) && std::is_same<Tag, bf16_tag>::value ? 0x3F80 : 0x3C00);
 
     stage(0, 0);
     dma_wait_all();
@@ -130,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             for (int t2 = 0; t2 < NDV; ++t2)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+            if (RS_MFMA) lacc[0] *= alpha;   // every register holds the same sum; only register 0 is read back
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
                     sacc[kb][i] = p;
-                    rs += p;
+                    if (!RS_MFMA) rs += p;
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                     pk[3] = pack2<Tag>(sacc[kb][8 * s + 6], sacc[kb][8 * s + 7]);
                     const s16x8 pb = *reinterpret_cast<s16x8*>(&pk);
                     const int key_a = 32 * kb + 16 * s + 4 * h + tq;  // rows of the first 4-row block; second is +8
+                    if (RS_MFMA) lacc = mfma32<Tag>(ones, pb, lacc);
 #pragma unroll
                     for (int dvb = 0; dvb < NDV; ++dvb) {
                         const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     }
 
     // ---- epilogue: normalise, store O (input dtype) and lse (fp32, natural log)
-    const float l_tot = l_run + wave_half_swap(l_run);
+    const float l_tot = RS_MFMA ? lacc[0] : l_run + wave_half_swap(l_run);
     if (qrow < n) {
         const float inv = 1.f / l_tot;
         uint16_t* orow = o + base + (size_t)qrow * D;
@@ -592,7 +604,9 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
     if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
     if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
-    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB>) : launch(fwd_mfma_kernel<Tag, D, false, KB>);
+    if (option(OPT_FWD_RS) != 0)
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true>);
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false>);
 }
 
 template <typename Tag, int D>

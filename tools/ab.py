@@ -13,11 +13,10 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("dkdv 4 waves x 64 keys", {"dkdv": 4}),
-    ("fwd_kb=2", {"fwd_kb": 2}),
-    ("dq 2x64-key sub-tiles per barrier", {"dq_kt": 2}),
+    ("fwd row sum on the matrix pipe", {"fwd_rs": 1}),
+
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs"]
 
 
 def main():
