@@ -601,9 +601,12 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
         return hipGetLastError();
     };
-    const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
-    if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
-    if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
+    // experimental schedules (sweep evidence only): built for bf16, d = 128, 64-key tiles; anything else runs lock-step
+    if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2) {
+        const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
+        if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
+        if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
+    }
     if (option(OPT_FWD_RS) != 0)
         return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true>);
     return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false>);
@@ -612,14 +615,10 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
-    const int stag = option(OPT_FWD_STAG);
+    const bool experimental = option(OPT_FWD_STAG) != 0 || option(OPT_FWD_PIPE) != 0;
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
-    if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
-    if (kb == 4) return launch_fwd_t<Tag, D, 4>(a, st);
-    // defaults: the staggered kernel keeps S and the packed P live across its half-step barriers, so at d = 128 it
-    // takes 64-key tiles (234 registers; 128-key tiles spill); the lock-step kernel prefers 128-key tiles
-    if (stag && D == 128) return launch_fwd_t<Tag, D, 2>(a, st);
-    return launch_fwd_t<Tag, D, 4>(a, st);
+    if (kb == 2 || experimental) return launch_fwd_t<Tag, D, 2>(a, st);   // the experimental schedules use 64-key tiles
+    return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key (LDS 128 KiB at d = 128)
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
