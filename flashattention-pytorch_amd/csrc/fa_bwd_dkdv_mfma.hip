@@ -15,7 +15,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool KREG>
 __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
@@ -63,6 +63,14 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     s16x8 vf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, (key * D + 16 * ks + 8 * h) * 2);
+    // KREG (d = 64 only: at d = 128 there is no room): the wave's K rows also stay in registers instead of being
+    // re-read from the LDS tile for every 32-query block
+    s16x8 kfr[KREG ? NKS : 1];
+    if (KREG) {
+        const buf_rsrc_t kk_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kfr[ks] = buf_load_frag(kk_rs, (key * D + 16 * ks + 8 * h) * 2);
+    }
     f32x16 dka[NDB], dva[NDB];
 #pragma unroll
     for (int t = 0; t < NDB; ++t)
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                 for (int ks = 0; ks < NKS; ++ks) {
                     const int ro = TileSwz<D>::off(r, 2 * ks + h);
                     const s16x8 qa = *reinterpret_cast<const s16x8*>(Qt + 32 * qb * 2 * D + ro);
-                    const s16x8 kf = *reinterpret_cast<const s16x8*>(Ks + ro + kofs);
+                    const s16x8 kf = KREG ? kfr[KREG ? ks : 0] : *reinterpret_cast<const s16x8*>(Ks + ro + kofs);
                     sacc = mfma32<Tag>(qa, kf, sacc);
                 }
 #pragma unroll
@@ -209,7 +217,11 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
                            (int)a.n, nkt, c, a.scale);
         return hipGetLastError();
     };
-    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false>);
+    if constexpr (D == 64) {
+        if (option(OPT_DKDV_KREG) != 0)
+            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true>);
+    }
+    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false>);
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {

@@ -14,9 +14,10 @@ import flashattention_lab_cuda as ext
 VARIANTS = [
     ("base", {}),
     ("fwd row sum on the matrix pipe", {"fwd_rs": 1}),
+    ("dkdv K rows in registers (d=64)", {"dkdv_kreg": 1}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg"]
 
 
 def main():
