@@ -23,7 +23,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA>
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -129,18 +129,31 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
             mx = fmaxf(mx, wave_half_swap(mx));
+            // Online-softmax bookkeeping.  LAZY (default): keep the stale running max while no row of the wave has grown
+            // past it by more than 2^8 (P then lies in (0, 256] instead of (0, 1]: the same relative precision in bf16 /
+            // f16 / f32, no overflow), and skip the O / l rescale for that tile — it is needed in the first tiles only.
+            // When any row does cross the threshold, EVERY lane moves to its exact new max and everything accumulated
+            // so far (O and l; P of this tile is not formed yet) is scaled exactly once.
             const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
-            const float mc = m_use * c_log2;
-            m_run = m_new;
-            // O rescale first (it only needs alpha), then per 32-key block: exp2 -> pack -> issue that block's P.V MFMAs.
-            // The MFMAs execute asynchronously, so the next block's exp2 / sum / pack (VALU) runs underneath them.
+            float mc;
+            bool rescale = true;
+            if (LAZY) rescale = __any((m_new - m_run) * c_log2 > 8.0f) != 0;   // m_run = -inf on the first tile -> true
+            if (rescale) {
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
+                mc = m_use * c_log2;
+                m_run = m_new;
 #pragma unroll
-            for (int t2 = 0; t2 < NDV; ++t2)
+                for (int t2 = 0; t2 < NDV; ++t2)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
-            if (RS_MFMA) lacc[0] *= alpha;   // every register holds the same sum; only register 0 is read back
+                    for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+                if (RS_MFMA) lacc[0] *= alpha;   // every register holds the same sum; only register 0 is read back
+                l_run *= alpha;
+            } else {
+                mc = m_run * c_log2;
+            }
+            // then per 32-key block: exp2 -> pack -> issue that block's P.V MFMAs (they execute asynchronously, so the
+            // next block's exp2 / sum / pack runs underneath them)
             float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                     }
                 }
             }
-            l_run = l_run * alpha + rs;
+            l_run += rs;
         }
         dma_wait_all();   // this wave's share of the next tile has landed ...
         __syncthreads();  // ... and so has everyone else's
@@ -608,8 +621,10 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     }
     if (option(OPT_FWD_RS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true>);
-    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true>);
+    if (option(OPT_FWD_EAGER) != 0)   // rescale every tile (the textbook order), for the A/B
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false>);
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true>);
 }
 
 template <typename Tag, int D>

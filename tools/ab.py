@@ -14,10 +14,10 @@ import flashattention_lab_cuda as ext
 VARIANTS = [
     ("base", {}),
     ("fwd row sum on the matrix pipe", {"fwd_rs": 1}),
-    ("dkdv K rows in registers (d=64)", {"dkdv_kreg": 1}),
+    ("fwd eager rescale (every tile)", {"fwd_eager": 1}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager"]
 
 
 def main():
