@@ -23,7 +23,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY>
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -98,14 +98,39 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
         const char* Vt = Kt + TILE_BYTES;
         {
             f32x16 sacc[KB];
+            if constexpr (!HS) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
+                for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
-                    sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
+                        sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
+                    }
+                }
+            } else {
+                // HS ("hand-scheduled" in source): left alone, hipcc sinks every LDS operand read to just before the MFMA
+                // that consumes it (ds_read, s_waitcnt, v_mfma per step), so each of the 8*KB steps eats the LDS latency.
+                // Here the K fragment of step j+2 is issued before MFMA j and sched_barrier(0) pins that order; the
+                // compiler still inserts the (counted) waits.
+                constexpr int NSTEP = KB * NKS;
+                auto kfrag = [&](int j) {
+                    return *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * (j / NKS) + r, 2 * (j % NKS) + h));
+                };
+                s16x8 ring[3];
+                ring[0] = kfrag(0);
+                ring[1] = kfrag(1);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NSTEP; ++j) {
+                    if (j + 2 < NSTEP) ring[(j + 2) % 3] = kfrag(j + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sacc[j / NKS] = mfma32<Tag>(ring[j % 3], qf[j % NKS], sacc[j / NKS]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- mask (diagonal tiles / ragged last tile only)
@@ -155,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
             // then per 32-key block: exp2 -> pack -> issue that block's P.V MFMAs (they execute asynchronously, so the
             // next block's exp2 / sum / pack runs underneath them)
             float rs = 0.f;
+            if constexpr (!HS) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -180,6 +206,46 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                         const s16x4 hi = lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1));
                         const s16x8 a = cat8(lo, hi);
                         oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+                    }
+                }
+            }
+            } else {
+                // exp2 / pack of block kb+1 is sliced between the P.V MFMAs of block kb (two elements = one packed dword
+                // per MFMA step), and the transposed V fragment of step t+1 is issued before MFMA t.
+                u32x4 pp[2][2];   // packed P of the block being consumed / being produced (static indices after unrolling)
+                auto exp_pair = [&](int kb, int m) {   // elements 2m, 2m+1 of block kb -> dword (m >> 2, m & 3)
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][2 * m], c_log2, -mc));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][2 * m + 1], c_log2, -mc));
+                    if (!RS_MFMA) rs += p0 + p1;
+                    pp[kb & 1][m >> 2][m & 3] = pack2<Tag>(p0, p1);
+                };
+                auto vfrag = [&](int kb, int t2) {     // A operand of step (s = t2 >> 2 ... ) of block kb
+                    const int s2 = t2 / NDV, dvb = t2 % NDV;
+                    const int key_a = 32 * kb + 16 * s2 + 4 * h + tq;
+                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+                    return cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
+                                lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
+                };
+                constexpr int PSTEP = 2 * NDV;          // MFMAs per 32-key block
+#pragma unroll
+                for (int m = 0; m < 8; ++m) exp_pair(0, m);
+                s16x8 vnext = vfrag(0, 0);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                    for (int t2 = 0; t2 < PSTEP; ++t2) {
+                        const s16x8 vcur = vnext;
+                        if (t2 + 1 < PSTEP) vnext = vfrag(kb, t2 + 1);
+                        else if (kb + 1 < KB) vnext = vfrag(kb + 1, 0);
+                        if (kb + 1 < KB) {                               // 8 pairs of block kb+1 over the PSTEP steps
+#pragma unroll
+                            for (int m = (8 * t2) / PSTEP; m < (8 * (t2 + 1)) / PSTEP; ++m) exp_pair(kb + 1, m);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[kb & 1][t2 / NDV]);
+                        if (RS_MFMA && (t2 % NDV) == 0) lacc = mfma32<Tag>(ones, pb, lacc);
+                        oacc[t2 % NDV] = mfma32<Tag>(vcur, pb, oacc[t2 % NDV]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -621,10 +687,12 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     }
     if (option(OPT_FWD_RS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false>);
     if (option(OPT_FWD_EAGER) != 0)   // rescale every tile (the textbook order), for the A/B
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false>);
-    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false>);
+    if (option(OPT_FWD_HS) != 0)
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true>);
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false>);
 }
 
 template <typename Tag, int D>

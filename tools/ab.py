@@ -13,11 +13,10 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("fwd row sum on the matrix pipe", {"fwd_rs": 1}),
-    ("fwd eager rescale (every tile)", {"fwd_eager": 1}),
+    ("fwd source-level software pipeline (operand prefetch)", {"fwd_hs": 1}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs"]
 
 
 def main():
