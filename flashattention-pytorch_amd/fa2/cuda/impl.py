@@ -1,83 +1,17 @@
-"""FA2 autograd wrapper over the HIP extension — counterpart of /root/reference/src/fa2/cuda/impl.py.
-
-Same public names and behaviour: `_load_ext()` looks the extension module up by name and caches it
-(reference :6-16), `_FA2CudaFn` saves (q, k, v, o, lse) and ignores `dlse` (reference :38-73),
-`fa2_cuda` accepts (B,H,N,d) or (BH,N,d) and returns tensors of the same rank (reference :75-85;
-the 3-D case uses the fixed `_merge_bh` of src/fa3/cuda/impl.py:18-22).
+"""FA2 front end of the HIP extension — same public names as /root/reference/src/fa2/cuda/impl.py
+(`_load_ext`, `_merge_bh`, `_split_bh`, `_split_bh_lse`, `_FA2CudaFn`, `fa2_cuda`), built from the shared pieces
+in `common/hip_autograd.py`.  Extension attributes used: `forward` / `backward` (csrc/common/torch.extension.cpp:73-83).
+3-D (BH,N,d) and 4-D (B,H,N,d) inputs are both accepted and come back with the same rank (the 3-D case follows the
+fixed `_merge_bh` of src/fa3/cuda/impl.py:18-22).
 """
-from importlib import import_module
+from common.hip_autograd import load_extension, make_attention_function, merge_bh, run_attention, split_bh
 
-import torch
-
-_ext = None
-
-
-def _load_ext():
-    global _ext
-    if _ext is not None:
-        return _ext
-    errors = []
-    for name in ("flashattention_lab_cuda", "flashattention_lab._C"):
-        try:
-            _ext = import_module(name)
-            return _ext
-        except Exception as exc:  # noqa: BLE001 - mirror the reference's lookup loop, but keep the reason
-            errors.append(f"{name}: {exc}")
-    raise ImportError("CUDA extension module not found (" + "; ".join(errors) + ")")
-
-
-def _merge_bh(x):
-    if x.dim() == 3:
-        return x, None
-    b, h, n, d = x.shape
-    return x.reshape(b * h, n, d), (b, h)
-
-
-def _split_bh(x, bh_shape):
-    if bh_shape is None:
-        return x
-    b, h = bh_shape
-    _, n, d = x.shape
-    return x.reshape(b, h, n, d)
-
-
-def _split_bh_lse(lse, bh_shape):
-    if bh_shape is None:
-        return lse
-    b, h = bh_shape
-    _, n = lse.shape
-    return lse.reshape(b, h, n)
-
-
-class _FA2CudaFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, k, v, causal, softmax_scale, br, bc):
-        ext = _load_ext()
-        if not q.is_cuda or not k.is_cuda or not v.is_cuda:
-            raise RuntimeError("Inputs must be CUDA tensors")
-        q = q.contiguous()
-        k = k.contiguous()
-        v = v.contiguous()
-        o, lse = ext.forward(q, k, v, bool(causal), float(softmax_scale), int(br), int(bc))
-        ctx.save_for_backward(q, k, v, o, lse)
-        ctx.causal = bool(causal)
-        ctx.softmax_scale = float(softmax_scale)
-        ctx.br = int(br)
-        ctx.bc = int(bc)
-        return o, lse
-
-    @staticmethod
-    def backward(ctx, do, dlse):
-        ext = _load_ext()
-        q, k, v, o, lse = ctx.saved_tensors
-        do = do.contiguous()
-        dq, dk, dv = ext.backward(q, k, v, o, do, lse, bool(ctx.causal), float(ctx.softmax_scale), int(ctx.br), int(ctx.bc))
-        return dq, dk, dv, None, None, None, None
+_load_ext = load_extension
+_merge_bh = merge_bh
+_split_bh = split_bh
+_split_bh_lse = split_bh
+_FA2CudaFn = make_attention_function("_FA2CudaFn", "forward", "backward", n_extra=0)
 
 
 def fa2_cuda(q, k, v, causal, softmax_scale, spec):
-    qb, bh_shape = _merge_bh(q)
-    kb, _ = _merge_bh(k)
-    vb, _ = _merge_bh(v)
-    o, lse = _FA2CudaFn.apply(qb, kb, vb, causal, softmax_scale, spec.br, spec.bc)
-    return _split_bh(o, bh_shape), _split_bh_lse(lse, bh_shape)
+    return run_attention(_FA2CudaFn, q, k, v, causal, softmax_scale, spec.br, spec.bc)

@@ -1,20 +1,8 @@
-"""Tile hints for FA2 — counterpart of /root/reference/src/fa2/spec.py.
+"""Tile hints for FA2 (`FA2Spec`, `pick_fa2_spec`) — see common/tile_hints.py for the table and why they are hints."""
+from common.tile_hints import make_spec_class, pick
 
-The reference's table (d <= 64 -> br=128, bc=128; else br=64, bc=128; num_warps=8) is kept
-field for field because callers construct and pass these objects; on MI355X they are HINTS ONLY: the
-HIP library picks its own wave64 tiling ("Tile table") and results are tile independent.
-"""
-from dataclasses import dataclass
+FA2Spec = make_spec_class("FA2Spec", with_stages=False)
 
 
-@dataclass(frozen=True)
-class FA2Spec:
-    br: int
-    bc: int
-    num_warps: int
-
-
-def pick_fa2_spec(head_dim: int) -> FA2Spec:
-    if head_dim <= 64:
-        return FA2Spec(br=128, bc=128, num_warps=8)
-    return FA2Spec(br=64, bc=128, num_warps=8)
+def pick_fa2_spec(head_dim: int):
+    return pick(FA2Spec, head_dim)

@@ -1,21 +1,8 @@
-"""Tile hints for FA3 — counterpart of /root/reference/src/fa3/spec.py.
+"""Tile hints for FA3 (`FA3Spec`, `pick_fa3_spec`) — see common/tile_hints.py for the table and why they are hints."""
+from common.tile_hints import make_spec_class, pick
 
-The reference's table (d <= 64 -> br=128, bc=128; else br=64, bc=128; num_warps=8; stages=2) is kept
-field for field because callers construct and pass these objects; on MI355X they are HINTS ONLY: the
-HIP library picks its own wave64 tiling ("Tile table") and results are tile independent.
-"""
-from dataclasses import dataclass
+FA3Spec = make_spec_class("FA3Spec", with_stages=True)
 
 
-@dataclass(frozen=True)
-class FA3Spec:
-    br: int
-    bc: int
-    num_warps: int
-    stages: int
-
-
-def pick_fa3_spec(head_dim: int) -> FA3Spec:
-    if head_dim <= 64:
-        return FA3Spec(br=128, bc=128, num_warps=8, stages=2)
-    return FA3Spec(br=64, bc=128, num_warps=8, stages=2)
+def pick_fa3_spec(head_dim: int):
+    return pick(FA3Spec, head_dim)
