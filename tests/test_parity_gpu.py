@@ -362,3 +362,37 @@ def test_forward_backward_capture_into_a_hip_graph(device):
     assert torch.equal(o, ref_o) and torch.equal(lse, ref_lse)
     for a, b in zip((dq, dk, dv), ref_g):
         assert torch.equal(a, b)
+
+
+def test_extreme_inputs_stay_finite_and_match(device):
+    """Large-magnitude scores (|s| ~ 1e3 after scaling), a tiny softmax_scale and N=1: no overflow / NaN, and the result
+    still matches the fp64 oracle at the reference's tolerance."""
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        q, k, v, do = make_qkv(2, 200, 64, dtype, seed=41)
+        q = (q.float() * 6).to(dtype)
+        k = (k.float() * 6).to(dtype)
+        for scale in (1.0, 1e-4):
+            rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, True, scale, math_dtype=torch.float64)
+            o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), True, scale, do=do.to(device))
+            for t in (o, lse, dq, dk, dv):
+                assert torch.isfinite(t.float()).all()
+            tol = dtype_tolerances(dtype)
+            torch.testing.assert_close(o.cpu(), ro, **tol)
+            torch.testing.assert_close(lse.cpu(), rlse, rtol=1e-3, atol=2e-3)
+    q1, k1, v1, do1 = make_qkv(3, 1, 128, torch.bfloat16, seed=42)
+    o, lse, dq, dk, dv = _run(2, q1.to(device), k1.to(device), v1.to(device), False, 0.1, do=do1.to(device))
+    assert torch.equal(o.cpu(), v1)                       # one key: softmax = 1, o = v exactly
+    # dS = P (dP - delta) vanishes up to the different fp32 summation orders of dP (MFMA) and delta (prep kernel)
+    assert torch.allclose(dv.cpu().float(), do1.float()) and dq.float().abs().max() < 1e-5 and dk.float().abs().max() < 1e-5
+
+
+def test_many_small_heads(device):
+    # BH far above the CU count with short sequences: exercises the block remap with a non-multiple-of-8 grid
+    bh, n, d = 1003, 96, 64
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=43)
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, True, d ** -0.5)
+    o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), True, d ** -0.5, do=do.to(device))
+    torch.testing.assert_close(o.cpu(), ro, rtol=5e-2, atol=5e-2)
+    assert max_abs(lse.cpu(), rlse) < 1e-3
+    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
+        torch.testing.assert_close(a.cpu(), b, rtol=5e-2, atol=5e-2)
