@@ -130,9 +130,14 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                     const s16x8 kf = KREG ? kfr[KREG ? ks : 0] : *reinterpret_cast<const s16x8*>(Ks + ro + kofs);
                     sacc = mfma32<Tag>(qa, kf, sacc);
                 }
+                if (need_mask) {   // wave-uniform: only diagonal / ragged blocks pay for the compare + select
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    sacc[i] = ((i & 3) + 8 * (i >> 2) < thr) ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                    for (int i = 0; i < 16; ++i)
+                        sacc[i] = ((i & 3) + 8 * (i >> 2) < thr) ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[i] = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll

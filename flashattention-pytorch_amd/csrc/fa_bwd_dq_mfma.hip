@@ -104,10 +104,15 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
                 // register i holds key k0 + 32 kb + 4 h + rc(i): one per-lane threshold, no branch
                 const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
                 const int thr = need_mask ? lim - (k0s + 32 * kb + 4 * h) : 64;
+                if (need_mask) {   // wave-uniform: only diagonal / ragged blocks pay for the compare + select
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
-                    pacc[i] = ((i & 3) + 8 * (i >> 2) > thr) ? 0.f : p * pacc[i];
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                        pacc[i] = ((i & 3) + 8 * (i >> 2) > thr) ? 0.f : p * pacc[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pacc[i] = __builtin_amdgcn_exp2f(sacc[i] * c_log2) * pacc[i];
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
