@@ -11,9 +11,9 @@ CONFIGS = {
     "C3: B=4 H=32 N=8192 d=128 bf16 causal": ["--batch", "4", "--heads", "32", "--seqlen", "8192", "--head-dim", "128", "--causal"],
 }
 VARIANTS = [
-    ("default (fwd 64-key tile; split bwd, 8-wave dK/dV)", {}),
+    ("default (fwd 128-key tiles, lazy rescale; split bwd, 8-wave dK/dV)", {}),
     ("fwd K/V tile 32 keys", {"FA_FWD_KB": "1"}),
-    ("fwd K/V tile 128 keys", {"FA_FWD_KB": "4"}),
+    ("fwd K/V tile 64 keys", {"FA_FWD_KB": "2"}),
     ("dK/dV 4 waves x 64 keys (512 regs/wave)", {"FA_DKDV": "w4"}),
     ("single-kernel bwd, dQ by float atomics", {"FA_BWD_VARIANT": "atomic"}),
 ]
