@@ -192,6 +192,28 @@ __device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int ro
     }
 }
 
+// ---- epilogue: a wave's 32 x D result tile, held "row on the lane" (lane (r, h) owns 4-element pieces at columns
+// 32 b + 8 g + 4 h of row r), goes through a wave-private LDS region and leaves as whole rows: 1 KiB contiguous per
+// store instruction instead of 64 scattered 16-byte pieces (the per-workgroup tail is store-issue bound).
+template <int D>
+__device__ __forceinline__ void store_rows_via_lds(char* wl, const u32x2 (&vals)[(D / 32) * 4], uint16_t* gdst, int row0,
+                                                   int n, int lane) {
+    constexpr int CPR = D / 8, RPI = 512 / D, ROWB = 2 * D;   // chunks per row, rows per 1-KiB store, row bytes
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<u32x2*>(wl + r * ROWB + 16 * ((4 * b + g) ^ (r & (CPR - 1) & 15)) + 8 * h) = vals[4 * b + g];
+    const int rl = lane / CPR, cc = lane - rl * CPR;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = RPI * i + rl;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wl + row * ROWB + 16 * (cc ^ (row & (CPR - 1) & 15)));
+        if (row0 + row < n) *reinterpret_cast<u32x4*>(gdst + (size_t)(row0 + row) * D + 8 * cc) = v;
+    }
+}
+
 // XCD-aware block remap: blocks that share blockIdx % 8 share an XCD (and its L2) under the
 // observed round-robin placement (speed only, never correctness).  Returns the logical id such that
 // consecutive logical ids [c*per, (c+1)*per) run on one XCD.  Bijective for any nblk.

@@ -263,19 +263,19 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
 
     // ---- epilogue: normalise, store O (input dtype) and lse (fp32, natural log)
     const float l_tot = RS_MFMA ? lacc[0] : l_run + wave_half_swap(l_run);
-    if (qrow < n) {
+    {
         const float inv = 1.f / l_tot;
-        uint16_t* orow = o + base + (size_t)qrow * D;
+        u32x2 vals[NDV * 4];
 #pragma unroll
         for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                u32x2 pk;
-                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
-                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * g + 4 * h) = pk;
+                vals[4 * dvb + g][0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
+                vals[4 * dvb + g][1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
             }
-        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+        // every wave is past the last barrier: the K/V buffers are dead, each wave takes 32 x D x 2 bytes of them
+        store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, o + base, q0 + 32 * w, n, lane);
+        if (qrow < n && h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
     }
 }
 
@@ -669,7 +669,8 @@ template <typename Tag, int D, int KB>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     const int nqt = (int)((a.n + BM - 1) / BM);
-    const size_t smem = 2 * 2 * (32 * KB) * D * 2;
+    size_t smem = 2 * 2 * (32 * KB) * D * 2;
+    if (smem < (size_t)8 * 32 * D * 2) smem = (size_t)8 * 32 * D * 2;   // the epilogue stages the 256 x D output tile in LDS
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_MFMA, st);
