@@ -23,7 +23,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS>
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -32,24 +32,36 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
+    // TPW query tiles per workgroup (persistent over the tiles of one (b,h)): the next tile's Q fragments and first
+    // K/V tile are fetched under the tail of the current one, so only the first tile of a workgroup pays the full
+    // prologue (all 256 CUs otherwise run their prologue / epilogue HBM bursts at the same time).  Non-causal: TPW
+    // consecutive tiles.  Causal (TPW <= 2): the heavy tile nqt-1-g and the light tile g — equal work per workgroup.
+    static_assert(TPW == 1 || KB == 4, "the persistent form stages the epilogue in one 128-key K/V buffer");
+    static_assert(!CAUSAL || TPW <= 2, "causal pairing is defined for two tiles");
+    const int gpb = (nqt + TPW - 1) / TPW;                     // workgroups per (b,h)
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nqt;
-    int qt = L - bh * nqt;
-    if (CAUSAL) qt = nqt - 1 - qt;  // heaviest query tiles first
-    const int q0 = qt * BM;
+    const int bh = L / gpb;
+    const int grp = L - bh * gpb;
+    auto tile_of = [&](int i) { return CAUSAL ? (i == 0 ? nqt - 1 - grp : grp) : grp * TPW + i; };
+    int ntile_wg = 0;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tt = tile_of(i);
+        if (CAUSAL ? (i == 0 || grp < nqt - 1 - grp) : (tt < nqt)) ntile_wg = i + 1;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int qrow = q0 + 32 * w + r;
     const size_t base = (size_t)bh * n * D;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][16 ks + 8 h .. +7]
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
     s16x8 qf[NKS];
+    auto load_q = [&](int qt_) {
+        const int row = qt_ * BM + 32 * w + r;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
-
-    const int kend = CAUSAL ? min(n, q0 + BM) : n;
-    const int ntiles = (kend + BN - 1) / BN;
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (row * D + 16 * ks + 8 * h) * 2);
+    };
+    load_q(tile_of(0));
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
@@ -62,18 +74,10 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     };
 
     f32x16 oacc[NDV];
-#pragma unroll
-    for (int t = 0; t < NDV; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
-    float m_run = -INFINITY;  // running max of the raw scores (before softmax_scale) of this lane's query row
-    float l_run = 0.f;        // this half-wave's share of the running sum (VALU row-sum variant)
+    float m_run, l_run;   // running max of the raw scores of this lane's query row; this half-wave's share of the row sum
     // RS_MFMA: the row sum rides the matrix pipe instead — one extra MFMA per k-step with an all-ones A operand gives
-    // sum_key P[q][key] in every register of `lacc` (col = this lane's query, both lane halves included).  The vector
-    // pipe is the busier one here (MFMA-busy 43 %), and the sum then uses exactly the rounded P that feeds P.V.
+    // sum_key P[q][key] in every register of `lacc` (col = this lane's query, both lane halves included).
     f32x16 lacc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
     s16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (short)(sizeof(Tag) && std::is_same<Tag, bf16_tag>::value ? 0x3F80 : 0x3C00);
@@ -85,14 +89,37 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     // lane-constant pieces of the transposed V read address
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
 
+    int gbase = 0;   // K/V tiles consumed so far by this workgroup: tile t of the current query tile sits in buffer (gbase + t) & 1
+    for (int it = 0; it < ntile_wg; ++it) {
+    const int q0 = tile_of(it) * BM;
+    const int qrow = q0 + 32 * w + r;
+    const bool has_next = it + 1 < ntile_wg;
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+    m_run = -INFINITY;
+    l_run = 0.f;
+    // what to fetch while tile t is being consumed: the next K/V tile of this query tile, or — on its last tile — the
+    // first K/V tile of the workgroup's next query tile (same (b,h), so the same rows 0 .. BN-1)
+    auto stage_next = [&](int t) {
+        const int nb = (gbase + t + 1) & 1;
+        if (t + 1 < ntiles) stage(nb, (t + 1) * BN);
+        else if (has_next) stage(nb, 0);
+    };
+
     // tiles this wave computes: under the causal mask a tile whose first key lies past the wave's last row is
     // skipped.  Two loops instead of an `if` inside one: a conditional accumulate makes hipcc carry the
     // accumulators through copies.
     const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
     for (int t = 0; t < ntiles_w; ++t) {
         const int k0 = t * BN;
-        const int cur = t & 1;
-        if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);  // nobody reads that buffer: all waves passed the last barrier
+        const int cur = (gbase + t) & 1;
+        stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
 
         const char* Kt = smem + cur * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
@@ -256,13 +283,16 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     }
     // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
     for (int t = ntiles_w; t < ntiles; ++t) {
-        if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        stage_next(t);
         dma_wait_all();
         __syncthreads();
     }
+    const int lastbuf = (gbase + ntiles - 1) & 1;   // buffer of the tile just finished: dead now, the epilogue's staging area
+    gbase += ntiles;
 
     // ---- epilogue: normalise, store O (input dtype) and lse (fp32, natural log)
     const float l_tot = RS_MFMA ? lacc[0] : l_run + wave_half_swap(l_run);
+    if (has_next) load_q(tile_of(it + 1));   // Q of the next tile is in flight while this tile's O goes out
     {
         const float inv = 1.f / l_tot;
         u32x2 vals[NDV * 4];
@@ -273,10 +303,14 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                 vals[4 * dvb + g][0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
                 vals[4 * dvb + g][1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
             }
-        // every wave is past the last barrier: the K/V buffers are dead, each wave takes 32 x D x 2 bytes of them
-        store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, o + base, q0 + 32 * w, n, lane);
+        // every wave is past the last barrier: that tile's buffer is dead, each wave takes 32 x D x 2 bytes of it
+        // (with TPW == 1 buffer 0 is used: it always holds at least 8 x 32 x D x 2 bytes, see the launcher)
+        char* stg = smem + (TPW == 1 ? 0 : lastbuf * 2 * TILE_BYTES) + w * 32 * D * 2;
+        store_rows_via_lds<D>(stg, vals, o + base, q0 + 32 * w, n, lane);
         if (qrow < n && h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
     }
+    if (has_next) __syncthreads();   // the staging area is the next tile's first DMA target
+    }   // query tiles of this workgroup
 }
 
 bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
@@ -688,12 +722,26 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     }
     if (option(OPT_FWD_RS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false, 1>);
     if (option(OPT_FWD_EAGER) != 0)   // rescale every tile (the textbook order), for the A/B
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false, 1>);
     if (option(OPT_FWD_HS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true>);
-    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true, 1>);
+    if constexpr (KB == 4) {
+        // query tiles per workgroup: measured winners (profiles/r01_tile_sweep.md) are 2 under the causal mask (heavy +
+        // light tile: equal work per workgroup) and at d = 64 (-13 %), 1 at d = 128 non-causal; option fwd_tpw overrides
+        int tpw = option(OPT_FWD_TPW);
+        if (tpw == 0) tpw = (a.causal || D == 64) ? 2 : 1;
+        if (tpw == 2) {
+            grid = dim3((unsigned)(((nqt + 1) / 2) * a.bh));
+            return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 2>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 2>);
+        }
+        if (tpw == 4 && !a.causal) {
+            grid = dim3((unsigned)(((nqt + 3) / 4) * a.bh));
+            return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 4>);
+        }
+    }
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1>);
 }
 
 template <typename Tag, int D>
