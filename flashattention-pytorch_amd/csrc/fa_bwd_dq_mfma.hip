@@ -15,7 +15,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KT>
+template <typename Tag, int D, bool CAUSAL, int KT, int TPW>
 __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -26,30 +26,36 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
+    // TPW query tiles per workgroup (see fa_fwd_mfma.hip): non-causal consecutive tiles, causal the heavy + light pair
+    static_assert(!CAUSAL || TPW <= 2, "causal pairing is defined for two tiles");
+    const int gpb = (nqt + TPW - 1) / TPW;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nqt;
-    int qt = L - bh * nqt;
-    if (CAUSAL) qt = nqt - 1 - qt;
-    const int q0 = qt * BM;
+    const int bh = L / gpb;
+    const int grp = L - bh * gpb;
+    auto tile_of = [&](int i) { return CAUSAL ? (i == 0 ? nqt - 1 - grp : grp) : grp * TPW + i; };
+    int ntile_wg = 0;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        if (CAUSAL ? (i == 0 || grp < nqt - 1 - grp) : (tile_of(i) < nqt)) ntile_wg = i + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int qrow = q0 + 32 * w + r;
     const size_t base = (size_t)bh * n * D;
 
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
     const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
     s16x8 qf[NKS], of[NKS];
+    float nl, nd;   // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
+    auto load_rows = [&](int qt_) {
+        const int row = qt_ * BM + 32 * w + r;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
-        of[ks] = buf_load_frag(o_rs, (qrow * D + 16 * ks + 8 * h) * 2);
-    }
-    // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
-    const float nl = qrow < n ? nlse[(size_t)bh * n + qrow] : -1e30f;
-    const float nd = qrow < n ? ndelta[(size_t)bh * n + qrow] : 0.f;
-
-    const int kend = CAUSAL ? min(n, q0 + BM) : n;
-    const int ntiles = (kend + BN - 1) / BN;
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = buf_load_frag(q_rs, (row * D + 16 * ks + 8 * h) * 2);
+            of[ks] = buf_load_frag(o_rs, (row * D + 16 * ks + 8 * h) * 2);
+        }
+        nl = row < n ? nlse[(size_t)bh * n + row] : -1e30f;
+        nd = row < n ? ndelta[(size_t)bh * n + row] : 0.f;
+    };
+    load_rows(tile_of(0));
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
@@ -62,10 +68,6 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     };
 
     f32x16 dqa[NDB];
-#pragma unroll
-    for (int t = 0; t < NDB; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
 
     stage(0, 0);
     dma_wait_all();
@@ -73,14 +75,31 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
 
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
 
+    int gbase = 0;   // K/V tiles consumed so far: tile t of the current query tile sits in buffer (gbase + t) & 1
+    for (int it = 0; it < ntile_wg; ++it) {
+    const int q0 = tile_of(it) * BM;
+    const int qrow = q0 + 32 * w + r;
+    const bool has_next = it + 1 < ntile_wg;
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+#pragma unroll
+    for (int t = 0; t < NDB; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqa[t][i] = 0.f;
+    auto stage_next = [&](int t) {   // next K/V tile of this query tile, or the first one of the next query tile
+        const int nb = (gbase + t + 1) & 1;
+        if (t + 1 < ntiles) stage(nb, (t + 1) * BN);
+        else if (has_next) stage(nb, 0);
+    };
+
     // tiles this wave computes: under the causal mask a tile whose first key lies past the wave's last row is
     // skipped.  Two loops instead of an `if` inside one: a conditional accumulate makes hipcc carry the
     // accumulators through copies.
     const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
     for (int t = 0; t < ntiles_w; ++t) {
         const int k0 = t * BN;
-        const int cur = t & 1;
-        if (t + 1 < ntiles) stage(cur ^ 1, k0 + BN);  // nobody reads that buffer: all waves passed the last barrier
+        const int cur = (gbase + t) & 1;
+        stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
 #pragma unroll 1
         for (int sub = 0; sub < KT; ++sub) {   // not unrolled: the body already sits at the register limit
             const int k0s = k0 + 64 * sub;                       // first key of this 64-key sub-tile
@@ -141,23 +160,31 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     }
     // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
     for (int t = ntiles_w; t < ntiles; ++t) {
-        if (t + 1 < ntiles) stage((t & 1) ^ 1, (t + 1) * BN);
+        stage_next(t);
         dma_wait_all();
         __syncthreads();
     }
+    gbase += ntiles;
 
-    if (qrow < n) {
-        uint16_t* drow = dq + base + (size_t)qrow * D;
+    {
+        u32x2 vals[NDB * 4];
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                u32x2 pk;
-                pk[0] = pack2_rn<Tag>(dqa[db][4 * g + 0] * scale, dqa[db][4 * g + 1] * scale);
-                pk[1] = pack2_rn<Tag>(dqa[db][4 * g + 2] * scale, dqa[db][4 * g + 3] * scale);
-                *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = pk;
+                vals[4 * db + g][0] = pack2_rn<Tag>(dqa[db][4 * g + 0] * scale, dqa[db][4 * g + 1] * scale);
+                vals[4 * db + g][1] = pack2_rn<Tag>(dqa[db][4 * g + 2] * scale, dqa[db][4 * g + 3] * scale);
             }
+        if (has_next) load_rows(tile_of(it + 1));   // the next tile's Q, dO, row constants fly while dQ goes out
+        if (qrow < n) {
+            uint16_t* drow = dq + base + (size_t)qrow * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = vals[4 * db + g];
+        }
     }
+    }   // query tiles of this workgroup
 }
 
 template <typename Tag, int D, int KT>
@@ -166,7 +193,12 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = 2 * 2 * (64 * KT) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
-    dim3 grid((unsigned)(nqt * a.bh));
+    // query tiles per workgroup: 2 under the causal mask (heavy + light pair: -9 ... -11 %), 1 otherwise (±1-2 %);
+    // option dq_tpw overrides (1 | 2)
+    int tpw = option(OPT_DQ_TPW);
+    if (tpw == 0) tpw = (KT == 1 && a.causal) ? 2 : 1;
+    if (KT != 1) tpw = 1;
+    dim3 grid((unsigned)(((nqt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -176,7 +208,11 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
                            a.scale);
         return hipGetLastError();
     };
-    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT>);
+    if constexpr (KT == 1) {
+        if (tpw == 2)
+            return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2>);
+    }
+    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1>);
 }
 
 // K/V tile of the dQ pass: 64 keys per barrier is the measured winner (2.98 vs 3.43 ms, profiles/r01_tile_sweep.md);

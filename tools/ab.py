@@ -13,11 +13,11 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("fwd 1 query tile per workgroup", {"fwd_tpw": 1}),
-    ("fwd 2 query tiles per workgroup", {"fwd_tpw": 2}),
+    ("fwd+dq 1 query tile per workgroup", {"fwd_tpw": 1, "dq_tpw": 1}),
+    ("fwd+dq 2 query tiles per workgroup", {"fwd_tpw": 2, "dq_tpw": 2}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw"]
 
 
 def main():
