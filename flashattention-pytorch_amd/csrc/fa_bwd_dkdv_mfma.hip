@@ -15,7 +15,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, bool KREG>
+template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW>
 __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
@@ -31,22 +31,30 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     char* Os = Qs + 2 * Q_BYTES;          // [2][64][D]   (dO)
     float* Ls = reinterpret_cast<float*>(Os + 2 * Q_BYTES);  // [2][ 64 x -lse/scale | 64 x -delta ]
 
+    // workgroup L works through TPW key tiles of one (b,h) (persistent: the next tile's K / V / first Q,dO tile are
+    // requested before this tile's dK, dV stores, so prologue and epilogue overlap).  Under the causal mask the pair is
+    // heavy + light (kt, nkt-1-kt): every workgroup then carries the same number of query tiles.
+    const int npair = (nkt + TPW - 1) / TPW;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nkt;
-    const int kt = L - bh * nkt;          // under the causal mask key tile 0 is the heaviest and is launched first
-    const int key0 = kt * BK;
+    const int bh = L / npair;
+    const int jp = L - bh * npair;
+    auto tile_of = [&](int ip) -> int {
+        if (TPW == 1) return jp;
+        const int t = CAUSAL ? (ip == 0 ? jp : nkt - 1 - jp) : TPW * jp + ip;
+        if (CAUSAL && ip > 0 && t <= jp) return -1;   // odd tile count: the middle tile is its own pair
+        return t < nkt ? t : -1;
+    };
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const size_t base = (size_t)bh * n * D;
     const size_t rbase = (size_t)bh * n;
-    const int kw0 = key0 + 32 * w;        // first key of this wave
-    const int key = kw0 + r;              // this lane's key
 
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
     const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * D * 2);
     const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * D * 2);
     const rsrc_s_t l_rs = make_rsrc_s(nlse + rbase, (unsigned)n * 4);
     const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w);
 
     auto stage = [&](int buf, int qs) {
@@ -57,35 +65,47 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
         if (w == 1) dma4_issue(d_rs, lds_addr_of(Ls + buf * 128 + 64), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
     };
 
-    // ---- prologue: K tile by LDS-DMA, V fragments to registers, first Q/dO tile
-    dma_stage_tile<D, BK, 8>(k_rs, Ks, key0, dma_voff, w);
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
     s16x8 vf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, (key * D + 16 * ks + 8 * h) * 2);
     // KREG (d = 64 only: at d = 128 there is no room): the wave's K rows also stay in registers instead of being
     // re-read from the LDS tile for every 32-query block
     s16x8 kfr[KREG ? NKS : 1];
-    if (KREG) {
-        const buf_rsrc_t kk_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+    // requests of one key tile: K tile by LDS-DMA, V fragments to registers, first Q/dO tile (buffer 0)
+    auto begin_tile = [&](int kt_) {
+        const int key0_ = kt_ * BK;
+        const int key_ = key0_ + 32 * w + r;
+        dma_stage_tile<D, BK, 8>(k_rs, Ks, key0_, dma_voff, w);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kfr[ks] = buf_load_frag(kk_rs, (key * D + 16 * ks + 8 * h) * 2);
-    }
+        for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, (key_ * D + 16 * ks + 8 * h) * 2);
+        if (KREG) {
+            const buf_rsrc_t kk_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) kfr[ks] = buf_load_frag(kk_rs, (key_ * D + 16 * ks + 8 * h) * 2);
+        }
+        stage(0, CAUSAL ? (key0_ / BQ) * BQ : 0);
+    };
+
+    begin_tile(tile_of(0));
+    dma_wait_all();
+    __syncthreads();
+
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+
+#pragma unroll 1
+    for (int ip = 0; ip < TPW; ++ip) {
+    const int kt = tile_of(ip);
+    if (TPW > 1 && kt < 0) break;
+    const int key0 = kt * BK;
+    const int kw0 = key0 + 32 * w;        // first key of this wave
+    const int key = kw0 + r;              // this lane's key
     f32x16 dka[NDB], dva[NDB];
 #pragma unroll
     for (int t = 0; t < NDB; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dka[t][i] = 0.f; dva[t][i] = 0.f; }
-
     const int qs_first = CAUSAL ? (key0 / BQ) * BQ : 0;   // earlier query tiles see none of this workgroup's keys
     const int ntile = (n - qs_first + BQ - 1) / BQ;
     // first tile this wave computes: earlier tiles hold only queries before the wave's first key (causal)
     const int it_first = CAUSAL ? (kw0 / BQ) - (qs_first / BQ) : 0;
-    stage(0, qs_first);
-    dma_wait_all();
-    __syncthreads();
-
-    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
 
     // feed-only iterations (see fa_fwd_mfma.hip: two loops instead of a conditional accumulate)
     for (int it = 0; it < min(it_first, ntile); ++it) {
@@ -187,7 +207,10 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
         __syncthreads();
     }
 
-    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV
+    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV.  Every wave is past the last barrier, so
+    // the K tile and both Q/dO buffers are free: the next key tile's loads go out ahead of the stores.
+    const int kt_next = (TPW > 1 && ip + 1 < TPW) ? tile_of(ip + 1) : -1;
+    if (TPW > 1 && kt_next >= 0) begin_tile(kt_next);
     if (key < n) {
         uint16_t* dkrow = dk + base + (size_t)key * D;
         uint16_t* dvrow = dv + base + (size_t)key * D;
@@ -204,6 +227,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                 *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * h) = b;
             }
     }
+    if (TPW > 1 && kt_next >= 0) {
+        dma_wait_all();
+        __syncthreads();
+    }
+    }
 }
 
 template <typename Tag, int D>
@@ -212,7 +240,10 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * 64 * D * 2 + 2 * 128 * sizeof(float);
     const float c = a.scale * 1.4426950408889634f;
-    dim3 grid((unsigned)(nkt * a.bh));
+    // key tiles per workgroup: option dkdv_tpw (1 | 2), default see DESIGN.md
+    int tpw = option(OPT_DKDV_TPW);
+    if (tpw == 0) tpw = a.causal ? 2 : 1;
+    dim3 grid((unsigned)(((nkt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -224,9 +255,11 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
     };
     if constexpr (D == 64) {
         if (option(OPT_DKDV_KREG) != 0)
-            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true>);
+            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1>);
     }
-    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false>);
+    if (tpw == 2)
+        return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2>);
+    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1>);
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {

@@ -13,11 +13,11 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("fwd+dq 1 query tile per workgroup", {"fwd_tpw": 1, "dq_tpw": 1}),
-    ("fwd+dq 2 query tiles per workgroup", {"fwd_tpw": 2, "dq_tpw": 2}),
+    ("dkdv 1 key tile per workgroup", {"dkdv_tpw": 1}),
+    ("dkdv 2 key tiles per workgroup", {"dkdv_tpw": 2}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw"]
 
 
 def main():
