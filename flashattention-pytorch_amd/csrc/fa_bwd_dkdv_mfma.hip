@@ -15,15 +15,16 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW>
+template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD>
 __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ nlse,
                                                                const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
                                                                uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
-                                                               float scale) {
-    constexpr int BK = 256, BQ = 64, NKS = D / 16, NDB = D / 32, CPR = D / 8;
+                                                               float scale, int dr) {
+    constexpr int BK = 256, BQ = 64, NKS = D / 16, NDB = D / 32;
+    const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int K_BYTES = BK * D * 2, Q_BYTES = BQ * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                      // [256][D]
@@ -46,20 +47,20 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     };
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * DR;
     const size_t rbase = (size_t)bh * n;
 
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * D * 2);
-    const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
+    const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * DR * 2);
+    const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * DR * 2);
     const rsrc_s_t l_rs = make_rsrc_s(nlse + rbase, (unsigned)n * 4);
     const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
-    const int dma_voff = dma_lane_voff<D>(lane, w);
+    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * DR * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w, DR);
 
     auto stage = [&](int buf, int qs) {
-        dma_stage_tile<D, BQ, 8>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w);
-        dma_stage_tile<D, BQ, 8>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w);
+        dma_stage_tile<D, BQ, 8>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w, DR);
+        dma_stage_tile<D, BQ, 8>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w, DR);
         // row constants: 64 floats each, one 4-byte LDS-DMA per lane (rows >= n read as 0: harmless, their dO is 0)
         if (w == 0) dma4_issue(l_rs, lds_addr_of(Ls + buf * 128), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
         if (w == 1) dma4_issue(d_rs, lds_addr_of(Ls + buf * 128 + 64), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
@@ -73,13 +74,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     auto begin_tile = [&](int kt_) {
         const int key0_ = kt_ * BK;
         const int key_ = key0_ + 32 * w + r;
-        dma_stage_tile<D, BK, 8>(k_rs, Ks, key0_, dma_voff, w);
+        dma_stage_tile<D, BK, 8>(k_rs, Ks, key0_, dma_voff, w, DR);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, (key_ * D + 16 * ks + 8 * h) * 2);
+        for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, frag_off(key_, 16 * ks + 8 * h, DR, PAD));
         if (KREG) {
-            const buf_rsrc_t kk_rs = make_rsrc(k + base, (unsigned)n * D * 2);
+            const buf_rsrc_t kk_rs = make_rsrc(k + base, (unsigned)n * DR * 2);
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kfr[ks] = buf_load_frag(kk_rs, (key_ * D + 16 * ks + 8 * h) * 2);
+            for (int ks = 0; ks < NKS; ++ks) kfr[ks] = buf_load_frag(kk_rs, frag_off(key_, 16 * ks + 8 * h, DR, PAD));
         }
         stage(0, CAUSAL ? (key0_ / BQ) * BQ : 0);
     };
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     const int kt_next = (TPW > 1 && ip + 1 < TPW) ? tile_of(ip + 1) : -1;
     if (TPW > 1 && kt_next >= 0) begin_tile(kt_next);
     if (key < n) {
-        uint16_t* dkrow = dk + base + (size_t)key * D;
-        uint16_t* dvrow = dv + base + (size_t)key * D;
+        uint16_t* dkrow = dk + base + (size_t)key * DR;
+        uint16_t* dvrow = dv + base + (size_t)key * DR;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
                 a[1] = pack2_rn<Tag>(dka[db][4 * g + 2] * scale, dka[db][4 * g + 3] * scale);
                 b[0] = pack2_rn<Tag>(dva[db][4 * g + 0], dva[db][4 * g + 1]);
                 b[1] = pack2_rn<Tag>(dva[db][4 * g + 2], dva[db][4 * g + 3]);
+                if (PAD && 32 * db + 8 * g + 4 * h >= DR) continue;   // padded columns (DR is a multiple of 8)
                 *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * h) = a;
                 *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * h) = b;
             }
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     }
 }
 
-template <typename Tag, int D>
+template <typename Tag, int D, bool PAD = false>
 static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     constexpr int BK = 256;
     const int nkt = (int)((a.n + BK - 1) / BK);
@@ -250,19 +252,23 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv,
-                           (int)a.n, nkt, c, a.scale);
+                           (int)a.n, nkt, c, a.scale, (int)a.d);
         return hipGetLastError();
     };
-    if constexpr (D == 64) {
+    if constexpr (D == 64 && !PAD) {
         if (option(OPT_DKDV_KREG) != 0)
-            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1>);
+            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1, PAD>);
     }
     if (tpw == 2)
-        return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2>);
-    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1>);
+        return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2, PAD>);
+    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1, PAD>);
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.d != 64 && a.d != 128) {   // head dims below the tile width: zero-padded inside the kernel
+        if (a.dtype == 2) return a.d > 64 ? launch_dkdv_t<bf16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, true>(a, nlse, ndelta, st);
+        return a.d > 64 ? launch_dkdv_t<f16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, true>(a, nlse, ndelta, st);
+    }
     if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64>(a, nlse, ndelta, st);
     return a.d == 128 ? launch_dkdv_t<f16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64>(a, nlse, ndelta, st);
 }

@@ -15,13 +15,14 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KT, int TPW>
+template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD>
 __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ nlse,
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dq,
-                                                             int n, int nqt, float c_log2, float scale) {
+                                                             int n, int nqt, float c_log2, float scale, int dr) {
+    const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int BM = 256, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
@@ -39,18 +40,18 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
         if (CAUSAL ? (i == 0 || grp < nqt - 1 - grp) : (tile_of(i) < nqt)) ntile_wg = i + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * DR;
 
-    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
-    const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
+    const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * DR * 2);
     s16x8 qf[NKS], of[NKS];
     float nl, nd;   // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
     auto load_rows = [&](int qt_) {
         const int row = qt_ * BM + 32 * w + r;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            qf[ks] = buf_load_frag(q_rs, (row * D + 16 * ks + 8 * h) * 2);
-            of[ks] = buf_load_frag(o_rs, (row * D + 16 * ks + 8 * h) * 2);
+            qf[ks] = buf_load_frag(q_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
+            of[ks] = buf_load_frag(o_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
         }
         nl = row < n ? nlse[(size_t)bh * n + row] : -1e30f;
         nd = row < n ? ndelta[(size_t)bh * n + row] : 0.f;
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     load_rows(tile_of(0));
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
-    const int dma_voff = dma_lane_voff<D>(lane, w);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w, DR);
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
-        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w);
-        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w, DR);
+        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR);
     };
 
     f32x16 dqa[NDB];
@@ -177,17 +178,20 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
             }
         if (has_next) load_rows(tile_of(it + 1));   // the next tile's Q, dO, row constants fly while dQ goes out
         if (qrow < n) {
-            uint16_t* drow = dq + base + (size_t)qrow * D;
+            uint16_t* drow = dq + base + (size_t)qrow * DR;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = vals[4 * db + g];
+                for (int g = 0; g < 4; ++g) {
+                    if (PAD && 32 * db + 8 * g + 4 * h >= DR) continue;   // padded columns (DR is a multiple of 8)
+                    *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = vals[4 * db + g];
+                }
         }
     }
     }   // query tiles of this workgroup
 }
 
-template <typename Tag, int D, int KT>
+template <typename Tag, int D, int KT, bool PAD = false>
 static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     constexpr int BM = 256;
     const int nqt = (int)((a.n + BM - 1) / BM);
@@ -205,14 +209,14 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
-                           a.scale);
+                           a.scale, (int)a.d);
         return hipGetLastError();
     };
     if constexpr (KT == 1) {
         if (tpw == 2)
-            return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2>);
+            return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD>);
     }
-    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1>);
+    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1, PAD>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1, PAD>);
 }
 
 // K/V tile of the dQ pass: 64 keys per barrier is the measured winner (2.98 vs 3.43 ms, profiles/r01_tile_sweep.md);
@@ -223,6 +227,10 @@ static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* 
 }
 
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.d != 64 && a.d != 128) {   // head dims below the tile width: zero-padded inside the kernel
+        if (a.dtype == 2) return a.d > 64 ? launch_dq_kt<bf16_tag, 128, 1, true>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 64, 1, true>(a, nlse, ndelta, st);
+        return a.d > 64 ? launch_dq_kt<f16_tag, 128, 1, true>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 64, 1, true>(a, nlse, ndelta, st);
+    }
     if (a.dtype == 2) return a.d == 128 ? launch_dq_t<bf16_tag, 128>(a, nlse, ndelta, st) : launch_dq_t<bf16_tag, 64>(a, nlse, ndelta, st);
     return a.d == 128 ? launch_dq_t<f16_tag, 128>(a, nlse, ndelta, st) : launch_dq_t<f16_tag, 64>(a, nlse, ndelta, st);
 }

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
     }
 }
 
-bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
+bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 128 && d % 8 == 0; }
 
 // workspace: [dq scratch fp32 (bh*n*d)] [nlse (bh*n)] [ndelta (bh*n)]
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
@@ -354,12 +354,13 @@ size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
 template <typename Tag, int D>
 static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     constexpr int BK = 256;
-    const size_t nel = (size_t)a.bh * a.n * D;
+    const size_t nel = (size_t)a.bh * a.n * a.d;
+    const bool pad = a.d != D;   // head dims below the tile width run the split backward only
     const long long rows = (long long)a.bh * a.n;
     float* dq_acc = reinterpret_cast<float*>(a.workspace);
     float* nlse = dq_acc + nel;
     float* ndelta = nlse + rows;
-    const bool fused = a.fused_dq != 0;
+    const bool fused = a.fused_dq != 0 && !pad;
     hipError_t e = hipSuccess;
     if (fused) {
         e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
@@ -368,14 +369,14 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     {
         ProfScope ps(K_BWD_DELTA, st);
         hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
-                           (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, D, 1.0f / a.scale);
+                           (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, (int)a.d, 1.0f / a.scale);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // dK/dV pass of the split backward: the 8-wave kernel (two waves per SIMD) where its register budget holds
     // is the default; FA_DKDV=w4 selects the 4-wave / 512-register kernel below (tile sweep evidence).
     const int dkdv_env = option(OPT_DKDV);
-    if (!fused && dkdv_env != 4) {
+    if (pad || (!fused && dkdv_env != 4)) {
         e = launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
         if (e != hipSuccess) return e;
         return launch_bwd_dq_mfma(a, nlse, ndelta, st);
@@ -409,8 +410,8 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st) {
-    if (a.dtype == 2) return a.d == 128 ? launch_bwd_t<bf16_tag, 128>(a, st) : launch_bwd_t<bf16_tag, 64>(a, st);
-    return a.d == 128 ? launch_bwd_t<f16_tag, 128>(a, st) : launch_bwd_t<f16_tag, 64>(a, st);
+    if (a.dtype == 2) return a.d > 64 ? launch_bwd_t<bf16_tag, 128>(a, st) : launch_bwd_t<bf16_tag, 64>(a, st);
+    return a.d > 64 ? launch_bwd_t<f16_tag, 128>(a, st) : launch_bwd_t<f16_tag, 64>(a, st);
 }
 
 }  // namespace fa

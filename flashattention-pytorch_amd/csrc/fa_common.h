@@ -141,13 +141,20 @@ __device__ __forceinline__ s16x8 buf_load_frag(buf_rsrc_t rsrc, int off) {
     u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     return *reinterpret_cast<s16x8*>(&t);
 }
+// Padded head dims: a tensor row holds `dr` <= D elements (dr a multiple of 8, so 16-byte chunks are either whole or
+// absent); tiles and MFMA shapes stay D wide and the missing chunks are requested at kOobOff, an offset the buffer
+// range check rejects, so they arrive as zeros like the rows past the tensor's end.  dr == D folds to the plain form.
+constexpr int kOobOff = (int)0x80000000u;
+__device__ __forceinline__ int frag_off(int row, int col, int dr, bool pad) {
+    return (pad && col >= dr) ? kOobOff : (row * dr + col) * 2;
+}
 template <int D>
-__device__ __forceinline__ int dma_lane_voff(int lane, int w) {
+__device__ __forceinline__ int dma_lane_voff(int lane, int w, int dr = D) {
     constexpr int RPP = 512 / D, CPR = D / 8;
     const int rl = lane / CPR, slot = lane - rl * CPR;
     const int row = (RPP * w + rl) & 15;
     const int ch = (TileSwz<D>::off(row, slot) - 2 * D * row) >> 4;
-    return rl * 2 * D + 16 * ch;
+    return (8 * ch < dr) ? rl * 2 * dr + 16 * ch : kOobOff;
 }
 // The DMA itself is issued from inline asm, so hipcc does not see it: with the builtin form hipcc treats every later
 // ds_read_b64_tr_b16 as possibly aliasing the pending LDS write and parks the wave on s_waitcnt vmcnt(0) in the
@@ -164,8 +171,12 @@ __device__ __forceinline__ rsrc_s_t make_rsrc_s(const void* base, unsigned bytes
     r[3] = 0x00020000u;
     return r;
 }
+// LDS byte address of a pointer into the workgroup's shared memory: the low half of its flat address (the high half
+// is the shared aperture).  Deliberately not a flat -> local address-space cast: its null check (high half != 0),
+// once the high half folds to the aperture register, is mis-selected by this hipcc ("Operand has incorrect register
+// class: V_CMP_NE_U32 0, src_shared_base").
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p);
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
 }
 __device__ __forceinline__ void dma16_issue(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
     unsigned keep;
@@ -179,16 +190,16 @@ __device__ __forceinline__ void dma4_issue(rsrc_s_t rsrc, unsigned lds_dst, int 
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// stage rows [row0, row0 + ROWS) of the tensor behind `rsrc` (row stride 2*D bytes) into the LDS tile at `tile`
+// stage rows [row0, row0 + ROWS) of the tensor behind `rsrc` (row stride 2*dr bytes) into the LDS tile at `tile`
 template <int D, int ROWS, int NW>
-__device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int row0, int voff, int w) {
+__device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int row0, int voff, int w, int dr = D) {
     constexpr int RPP = 512 / D, PIECES = ROWS / RPP, PER_WAVE = PIECES / NW;
     static_assert(PIECES % NW == 0 && (RPP * NW) % 16 == 0, "tile does not split evenly over the waves");
     const unsigned t0 = lds_addr_of(tile);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
         const int pc = w + NW * j;
-        dma16_issue(rsrc, t0 + pc * 1024, voff, __builtin_amdgcn_readfirstlane((row0 + RPP * pc) * 2 * D));
+        dma16_issue(rsrc, t0 + pc * 1024, voff, __builtin_amdgcn_readfirstlane((row0 + RPP * pc) * 2 * dr));
     }
 }
 
@@ -197,7 +208,7 @@ __device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int ro
 // store instruction instead of 64 scattered 16-byte pieces (the per-workgroup tail is store-issue bound).
 template <int D>
 __device__ __forceinline__ void store_rows_via_lds(char* wl, const u32x2 (&vals)[(D / 32) * 4], uint16_t* gdst, int row0,
-                                                   int n, int lane) {
+                                                   int n, int lane, int dr = D) {
     constexpr int CPR = D / 8, RPI = 512 / D, ROWB = 2 * D;   // chunks per row, rows per 1-KiB store, row bytes
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -210,7 +221,7 @@ __device__ __forceinline__ void store_rows_via_lds(char* wl, const u32x2 (&vals)
     for (int i = 0; i < 32 / RPI; ++i) {
         const int row = RPI * i + rl;
         const u32x4 v = *reinterpret_cast<const u32x4*>(wl + row * ROWB + 16 * (cc ^ (row & (CPR - 1) & 15)));
-        if (row0 + row < n) *reinterpret_cast<u32x4*>(gdst + (size_t)(row0 + row) * D + 8 * cc) = v;
+        if (row0 + row < n && 8 * cc < dr) *reinterpret_cast<u32x4*>(gdst + (size_t)(row0 + row) * dr + 8 * cc) = v;
     }
 }
 

@@ -23,11 +23,12 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW>
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                          float scale) {
+                                                          float scale, int dr) {
+    const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
@@ -51,26 +52,26 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * DR;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][16 ks + 8 h .. +7]
-    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
     s16x8 qf[NKS];
     auto load_q = [&](int qt_) {
         const int row = qt_ * BM + 32 * w + r;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (row * D + 16 * ks + 8 * h) * 2);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
     };
     load_q(tile_of(0));
 
     // K / V tiles arrive by LDS-DMA (no staging registers); rows >= n read as zero
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
-    const int dma_voff = dma_lane_voff<D>(lane, w);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w, DR);
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
-        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w);
-        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w, DR);
+        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR);
     };
 
     f32x16 oacc[NDV];
@@ -306,14 +307,14 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
         // every wave is past the last barrier: that tile's buffer is dead, each wave takes 32 x D x 2 bytes of it
         // (with TPW == 1 buffer 0 is used: it always holds at least 8 x 32 x D x 2 bytes, see the launcher)
         char* stg = smem + (TPW == 1 ? 0 : lastbuf * 2 * TILE_BYTES) + w * 32 * D * 2;
-        store_rows_via_lds<D>(stg, vals, o + base, q0 + 32 * w, n, lane);
+        store_rows_via_lds<D>(stg, vals, o + base, q0 + 32 * w, n, lane, DR);
         if (qrow < n && h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
     }
     if (has_next) __syncthreads();   // the staging area is the next tile's first DMA target
     }   // query tiles of this workgroup
 }
 
-bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && (d == 64 || d == 128); }
+bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 128 && d % 8 == 0; }
 
 // ------------------------------------------------------------------------------------------------
 // Staggered variant (FA_FWD_STAG=1; NOT the default: measured 2.58 ms vs 2.1-2.2 ms for the lock-step kernel at
@@ -329,7 +330,7 @@ template <typename Tag, int D, bool CAUSAL, int KB>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale) {
+                                                               float scale, int /*dr: whole tile widths only*/) {
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
@@ -502,7 +503,7 @@ template <typename Tag, int D, bool CAUSAL, int KB>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale) {
+                                                               float scale, int /*dr: whole tile widths only*/) {
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* _
 // FA_FWD_KB=1|2|4 overrides it for the sweep (1 only at d = 128).
 static int fwd_kb_override() { return option(OPT_FWD_KB); }
 
-template <typename Tag, int D, int KB>
+template <typename Tag, int D, int KB, bool PAD = false>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     const int nqt = (int)((a.n + BM - 1) / BM);
@@ -712,21 +713,23 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale);
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, (int)a.d);
         return hipGetLastError();
     };
     // experimental schedules (sweep evidence only): built for bf16, d = 128, 64-key tiles; anything else runs lock-step
-    if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2) {
+    if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2 && !PAD) {
         const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
         if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
         if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     }
+    if constexpr (!PAD) {   // sweep variants exist for whole tile widths only
     if (option(OPT_FWD_RS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false, 1>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false, 1, PAD>);
     if (option(OPT_FWD_EAGER) != 0)   // rescale every tile (the textbook order), for the A/B
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false, 1>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false, 1, PAD>);
     if (option(OPT_FWD_HS) != 0)
-        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true, 1>);
+        return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true, 1, PAD>);
+    }
     if constexpr (KB == 4) {
         // query tiles per workgroup: measured winners (profiles/r01_tile_sweep.md) are 2 under the causal mask (heavy +
         // light tile: equal work per workgroup) and at d = 64 (-13 %), 1 at d = 128 non-causal; option fwd_tpw overrides
@@ -734,14 +737,16 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         if (tpw == 0) tpw = (a.causal || D == 64) ? 2 : 1;
         if (tpw == 2) {
             grid = dim3((unsigned)(((nqt + 1) / 2) * a.bh));
-            return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 2>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 2>);
+            return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 2, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 2, PAD>);
         }
-        if (tpw == 4 && !a.causal) {
-            grid = dim3((unsigned)(((nqt + 3) / 4) * a.bh));
-            return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 4>);
+        if constexpr (!PAD) {
+            if (tpw == 4 && !a.causal) {
+                grid = dim3((unsigned)(((nqt + 3) / 4) * a.bh));
+                return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 4, PAD>);
+            }
         }
     }
-    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 1>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1>);
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD>);
 }
 
 template <typename Tag, int D>
@@ -754,6 +759,10 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
+    if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
+        if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
+        return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
+    }
     if (a.dtype == 2) return a.d == 128 ? launch_fwd_kb<bf16_tag, 128>(a, st) : launch_fwd_kb<bf16_tag, 64>(a, st);
     return a.d == 128 ? launch_fwd_kb<f16_tag, 128>(a, st) : launch_fwd_kb<f16_tag, 64>(a, st);
 }

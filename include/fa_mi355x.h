@@ -50,7 +50,8 @@ extern "C" {
 #define FA_DTYPE_BF16 2
 
 /* Which implementation the dispatcher picks (fa_set_kernel_mode): AUTO = MFMA bf16/f16 kernels
- * when dtype is 16-bit and d is 64 or 128, exact-f32 MFMA kernels otherwise. */
+ * when dtype is 16-bit and d is a multiple of 8 up to 128 (64 / 128 wide tiles, narrower rows zero-padded in the kernel),
+ * exact-f32 MFMA kernels otherwise. */
 #define FA_MODE_AUTO 0
 #define FA_MODE_F32_GENERIC 1
 #define FA_MODE_BWD_ATOMIC 2 /* as AUTO, but the 16-bit backward is the single-kernel variant with float-atomic dQ */

@@ -55,6 +55,8 @@ def test_hip_matches_reference_golden_vectors(tag, device):
 SHAPES = [
     (1, 1, 16), (2, 7, 32), (3, 33, 64), (2, 64, 64), (2, 65, 128), (1, 128, 128), (2, 255, 64), (2, 256, 128),
     (1, 300, 40), (1, 300, 48), (2, 513, 64), (1, 1024, 128), (1, 200, 256), (1, 100, 8), (1, 77, 72),
+    # head dims below the MFMA tile width (zero-padded inside the kernels), several query / key tiles deep
+    (2, 513, 96), (1, 700, 80), (2, 1100, 120), (3, 600, 24), (1, 1030, 56),
 ]
 
 
@@ -234,10 +236,11 @@ def test_backward_ignores_dlse_and_runs_on_current_stream(device):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-def test_generic_and_mfma_paths_agree(causal, device):
+@pytest.mark.parametrize("d", [128, 40, 104])
+def test_generic_and_mfma_paths_agree(causal, d, device):
     import flashattention_lab_cuda as ext
 
-    q, k, v, do = (t.to(device) for t in make_qkv(2, 333, 128, torch.bfloat16, seed=9))
+    q, k, v, do = (t.to(device) for t in make_qkv(2, 333 if d == 128 else 777, d, torch.bfloat16, seed=9))
     o_a, lse_a, dq_a, dk_a, dv_a = _run(2, q, k, v, causal, 0.09, do=do)
     old = ext.set_kernel_mode(1)
     try:
