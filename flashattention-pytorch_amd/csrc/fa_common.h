@@ -102,6 +102,22 @@ template <> __device__ __forceinline__ void mfma32_v<f16_tag>(s16x8 a, s16x8 b, 
 __device__ __forceinline__ void mfma_result_fence(f32x16& c) { asm volatile("s_nop 11" : "+v"(c)); }
 __device__ __forceinline__ void mfma_result_fence(f32x16& c, f32x16& d) { asm volatile("s_nop 11" : "+v"(c), "+v"(d)); }
 
+// Multiply an accumulator tile by a per-lane scalar while it stays in the accumulation registers.  For the kernels
+// that run one wave per SIMD with their MFMA accumulators in AGPRs (D = 256): a plain `c *= alpha` is a VALU use, for
+// which hipcc copies every accumulator to a VGPR and back on EVERY trip of the tile loop, taken or not.  The caller
+// pads the MFMA -> v_accvgpr_read hazard (acc_scale_begin) because hipcc inserts no wait states around inline asm.
+__device__ __forceinline__ void acc_scale_begin() { asm volatile("s_nop 15\n\ts_nop 3"); }
+__device__ __forceinline__ void acc_scale_end() { asm volatile("s_nop 4"); }
+__device__ __forceinline__ void acc_scale(f32x16& c, float alpha) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float x = c[i], t;
+        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                     : "+a"(x), "=&v"(t) : "v"(alpha));
+        c[i] = x;
+    }
+}
+
 __device__ __forceinline__ float wave_half_swap(float x) {  // value held by lane ^ 32
     return __shfl_xor(x, 32, 64);
 }
@@ -114,6 +130,9 @@ __device__ __forceinline__ float wave_half_swap(float x) {  // value held by lan
 template <int D> struct TileSwz;
 template <> struct TileSwz<128> {
     static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+};
+template <> struct TileSwz<256> {   // 512-byte rows: the bank of a chunk is its index mod 16, so the 128-wide pattern repeats
+    static __device__ __forceinline__ int off(int row, int ch) { return 512 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 };
 template <> struct TileSwz<64> {
     static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
@@ -191,15 +210,19 @@ __device__ __forceinline__ void dma4_issue(rsrc_s_t rsrc, unsigned lds_dst, int 
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // stage rows [row0, row0 + ROWS) of the tensor behind `rsrc` (row stride 2*dr bytes) into the LDS tile at `tile`
+// (D = 256 with 4 waves: a wave's pieces alternate between two row classes mod 16, RPP * NW = 8; `voff_b` =
+// dma_lane_voff<D>(lane, w + NW, dr) serves the odd ones.)
 template <int D, int ROWS, int NW>
-__device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int row0, int voff, int w, int dr = D) {
+__device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int row0, int voff, int w, int dr = D,
+                                               int voff_b = 0) {
     constexpr int RPP = 512 / D, PIECES = ROWS / RPP, PER_WAVE = PIECES / NW;
-    static_assert(PIECES % NW == 0 && (RPP * NW) % 16 == 0, "tile does not split evenly over the waves");
+    static_assert(PIECES % NW == 0 && ((RPP * NW) % 16 == 0 || RPP * NW == 8), "tile does not split evenly over the waves");
     const unsigned t0 = lds_addr_of(tile);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
         const int pc = w + NW * j;
-        dma16_issue(rsrc, t0 + pc * 1024, voff, __builtin_amdgcn_readfirstlane((row0 + RPP * pc) * 2 * dr));
+        const int vo = ((RPP * NW) % 16 != 0 && (j & 1)) ? voff_b : voff;
+        dma16_issue(rsrc, t0 + pc * 1024, vo, __builtin_amdgcn_readfirstlane((row0 + RPP * pc) * 2 * dr));
     }
 }
 

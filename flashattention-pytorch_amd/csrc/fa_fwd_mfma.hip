@@ -24,12 +24,13 @@
 namespace fa {
 
 template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD>
-__global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
                                                           float scale, int dr) {
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
-    constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
+    // D = 256: 4 waves, one per SIMD, with the whole 512-register file each (Q fragments 64 + O^T 128 registers)
+    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -68,10 +69,11 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
     const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, DR);
+    const int dma_voff_b = D == 256 ? dma_lane_voff<D>(lane, w + NW, DR) : 0;
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
-        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w, DR);
-        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR);
+        dma_stage_tile<D, BN, NW>(k_rs, kb_, k0, dma_voff, w, DR, dma_voff_b);
+        dma_stage_tile<D, BN, NW>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR, dma_voff_b);
     };
 
     f32x16 oacc[NDV];
@@ -196,10 +198,17 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
                 mc = m_use * c_log2;
                 m_run = m_new;
+                if constexpr (D == 256) {   // accumulators live in AGPRs: scale them in place (fa_common.h)
+                    acc_scale_begin();
 #pragma unroll
-                for (int t2 = 0; t2 < NDV; ++t2)
+                    for (int t2 = 0; t2 < NDV; ++t2) acc_scale(oacc[t2], alpha);
+                    acc_scale_end();
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+                    for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+                }
                 if (RS_MFMA) lacc[0] *= alpha;   // every register holds the same sum; only register 0 is read back
                 l_run *= alpha;
             } else {
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const uint16_t* __rest
     }   // query tiles of this workgroup
 }
 
-bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 128 && d % 8 == 0; }
+bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 256 && d % 8 == 0; }
 
 // ------------------------------------------------------------------------------------------------
 // Staggered variant (FA_FWD_STAG=1; NOT the default: measured 2.58 ms vs 2.1-2.2 ms for the lock-step kernel at
@@ -702,17 +711,17 @@ static int fwd_kb_override() { return option(OPT_FWD_KB); }
 
 template <typename Tag, int D, int KB, bool PAD = false>
 static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
-    constexpr int BM = 256;
+    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW;
     const int nqt = (int)((a.n + BM - 1) / BM);
     size_t smem = 2 * 2 * (32 * KB) * D * 2;
-    if (smem < (size_t)8 * 32 * D * 2) smem = (size_t)8 * 32 * D * 2;   // the epilogue stages the 256 x D output tile in LDS
+    if (smem < (size_t)NW * 32 * D * 2) smem = (size_t)NW * 32 * D * 2;   // the epilogue stages the BM x D output tile in LDS
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, (int)a.d);
         return hipGetLastError();
     };
@@ -722,7 +731,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
         if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
     }
-    if constexpr (!PAD) {   // sweep variants exist for whole tile widths only
+    if constexpr (!PAD && D != 256) {   // sweep variants exist for the 64 / 128 tile widths only
     if (option(OPT_FWD_RS) != 0)
         return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, true, true, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, true, true, false, 1, PAD>);
     if (option(OPT_FWD_EAGER) != 0)   // rescale every tile (the textbook order), for the A/B
@@ -735,6 +744,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         // light tile: equal work per workgroup) and at d = 64 (-13 %), 1 at d = 128 non-causal; option fwd_tpw overrides
         int tpw = option(OPT_FWD_TPW);
         if (tpw == 0) tpw = (a.causal || D == 64) ? 2 : 1;
+        if (D == 256) tpw = 1;
         if (tpw == 2) {
             grid = dim3((unsigned)(((nqt + 1) / 2) * a.bh));
             return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 2, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 2, PAD>);
@@ -759,6 +769,10 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
+    if (a.d > 128) {   // 256-wide tiles of 64 keys, 4 waves (one per SIMD)
+        if (a.dtype == 2) return a.d == 256 ? launch_fwd_t<bf16_tag, 256, 2, false>(a, st) : launch_fwd_t<bf16_tag, 256, 2, true>(a, st);
+        return a.d == 256 ? launch_fwd_t<f16_tag, 256, 2, false>(a, st) : launch_fwd_t<f16_tag, 256, 2, true>(a, st);
+    }
     if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);

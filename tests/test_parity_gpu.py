@@ -57,6 +57,8 @@ SHAPES = [
     (1, 300, 40), (1, 300, 48), (2, 513, 64), (1, 1024, 128), (1, 200, 256), (1, 100, 8), (1, 77, 72),
     # head dims below the MFMA tile width (zero-padded inside the kernels), several query / key tiles deep
     (2, 513, 96), (1, 700, 80), (2, 1100, 120), (3, 600, 24), (1, 1030, 56),
+    # 256-wide tiles (4 waves, one per SIMD) and head dims padded up to them
+    (2, 700, 256), (1, 1000, 192), (2, 300, 136), (1, 129, 248),
 ]
 
 
