@@ -16,14 +16,15 @@
 namespace fa {
 
 template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD>
-__global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ nlse,
                                                                const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
                                                                uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
                                                                float scale, int dr) {
-    constexpr int BK = 256, BQ = 64, NKS = D / 16, NDB = D / 32;
+    // D = 256: 4 waves (one per SIMD, 512 registers: dK^T and dV^T alone are 256), 128 keys, query tiles of 32 rows
+    constexpr int NW = D == 256 ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64, NKS = D / 16, NDB = D / 32;
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int K_BYTES = BK * D * 2, Q_BYTES = BQ * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,10 +58,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
     const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * DR * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, DR);
+    const int dma_voff_b = D == 256 ? dma_lane_voff<D>(lane, w + NW, DR) : 0;
 
     auto stage = [&](int buf, int qs) {
-        dma_stage_tile<D, BQ, 8>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w, DR);
-        dma_stage_tile<D, BQ, 8>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w, DR);
+        dma_stage_tile<D, BQ, NW>(q_rs, Qs + buf * Q_BYTES, qs, dma_voff, w, DR, dma_voff_b);
+        dma_stage_tile<D, BQ, NW>(o_rs, Os + buf * Q_BYTES, qs, dma_voff, w, DR, dma_voff_b);
         // row constants: 64 floats each, one 4-byte LDS-DMA per lane (rows >= n read as 0: harmless, their dO is 0)
         if (w == 0) dma4_issue(l_rs, lds_addr_of(Ls + buf * 128), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
         if (w == 1) dma4_issue(d_rs, lds_addr_of(Ls + buf * 128 + 64), lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
     auto begin_tile = [&](int kt_) {
         const int key0_ = kt_ * BK;
         const int key_ = key0_ + 32 * w + r;
-        dma_stage_tile<D, BK, 8>(k_rs, Ks, key0_, dma_voff, w, DR);
+        dma_stage_tile<D, BK, NW>(k_rs, Ks, key0_, dma_voff, w, DR, dma_voff_b);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) vf[ks] = buf_load_frag(v_rs, frag_off(key_, 16 * ks + 8 * h, DR, PAD));
         if (KREG) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
         const float* Lt = Ls + cur * 128;
 
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < BQ / 32; ++qb) {
             // ---- S' = Q K^T - lse/scale (row constants as the initial accumulator), P = exp2(c S') packed to 16 bit,
             // then dP' = dO V^T - delta and dS = P dP'.  One chain at a time: at D = 128 the wave has ~96 registers
             // beside the resident dK^T / dV^T / V, and two live f32 tiles plus their operand prefetch do not fit.
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(512, 2) void bwd_dkdv_mfma_kernel(const uint16_t* _
 
 template <typename Tag, int D, bool PAD = false>
 static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    constexpr int BK = 256;
+    constexpr int NW = D == 256 ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64;
     const int nkt = (int)((a.n + BK - 1) / BK);
-    const size_t smem = (size_t)BK * D * 2 + 4 * 64 * D * 2 + 2 * 128 * sizeof(float);
+    const size_t smem = (size_t)BK * D * 2 + 4 * BQ * D * 2 + 2 * 128 * sizeof(float);
     const float c = a.scale * 1.4426950408889634f;
     // key tiles per workgroup: option dkdv_tpw (1 | 2), default see DESIGN.md
     int tpw = option(OPT_DKDV_TPW);
@@ -250,7 +252,7 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv,
                            (int)a.n, nkt, c, a.scale, (int)a.d);
         return hipGetLastError();
@@ -265,6 +267,10 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
+        if (a.dtype == 2) return a.d == 256 ? launch_dkdv_t<bf16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 256, true>(a, nlse, ndelta, st);
+        return a.d == 256 ? launch_dkdv_t<f16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 256, true>(a, nlse, ndelta, st);
+    }
     if (a.d != 64 && a.d != 128) {   // head dims below the tile width: zero-padded inside the kernel
         if (a.dtype == 2) return a.d > 64 ? launch_dkdv_t<bf16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, true>(a, nlse, ndelta, st);
         return a.d > 64 ? launch_dkdv_t<f16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, true>(a, nlse, ndelta, st);

@@ -16,14 +16,15 @@
 namespace fa {
 
 template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD>
-__global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ nlse,
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dq,
                                                              int n, int nqt, float c_log2, float scale, int dr) {
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
-    constexpr int BM = 256, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
+    // D = 256: 4 waves, one per SIMD, with the whole 512-register file each (Q, dO fragments 128 + dQ^T 128 registers)
+    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -62,10 +63,11 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
     const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, DR);
+    const int dma_voff_b = D == 256 ? dma_lane_voff<D>(lane, w + NW, DR) : 0;
     auto stage = [&](int buf, int k0) {
         char* kb_ = smem + buf * 2 * TILE_BYTES;
-        dma_stage_tile<D, BN, 8>(k_rs, kb_, k0, dma_voff, w, DR);
-        dma_stage_tile<D, BN, 8>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR);
+        dma_stage_tile<D, BN, NW>(k_rs, kb_, k0, dma_voff, w, DR, dma_voff_b);
+        dma_stage_tile<D, BN, NW>(v_rs, kb_ + TILE_BYTES, k0, dma_voff, w, DR, dma_voff_b);
     };
 
     f32x16 dqa[NDB];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void bwd_dq_mfma_kernel(const uint16_t* __r
 
 template <typename Tag, int D, int KT, bool PAD = false>
 static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    constexpr int BM = 256;
+    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW;
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = 2 * 2 * (64 * KT) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
@@ -201,18 +203,18 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
     // option dq_tpw overrides (1 | 2)
     int tpw = option(OPT_DQ_TPW);
     if (tpw == 0) tpw = (KT == 1 && a.causal) ? 2 : 1;
-    if (KT != 1) tpw = 1;
+    if (KT != 1 || D == 256) tpw = 1;
     dim3 grid((unsigned)(((nqt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
                            a.scale, (int)a.d);
         return hipGetLastError();
     };
-    if constexpr (KT == 1) {
+    if constexpr (KT == 1 && D != 256) {
         if (tpw == 2)
             return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD>);
     }
@@ -227,6 +229,10 @@ static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* 
 }
 
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
+        if (a.dtype == 2) return a.d == 256 ? launch_dq_kt<bf16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 256, 1, true>(a, nlse, ndelta, st);
+        return a.d == 256 ? launch_dq_kt<f16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 256, 1, true>(a, nlse, ndelta, st);
+    }
     if (a.d != 64 && a.d != 128) {   // head dims below the tile width: zero-padded inside the kernel
         if (a.dtype == 2) return a.d > 64 ? launch_dq_kt<bf16_tag, 128, 1, true>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 64, 1, true>(a, nlse, ndelta, st);
         return a.d > 64 ? launch_dq_kt<f16_tag, 128, 1, true>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 64, 1, true>(a, nlse, ndelta, st);

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
     }
 }
 
-bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 128 && d % 8 == 0; }
+bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 256 && d % 8 == 0; }
 
 // workspace: [dq scratch fp32 (bh*n*d)] [nlse (bh*n)] [ndelta (bh*n)]
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
@@ -355,7 +355,7 @@ template <typename Tag, int D>
 static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     constexpr int BK = 256;
     const size_t nel = (size_t)a.bh * a.n * a.d;
-    const bool pad = a.d != D;   // head dims below the tile width run the split backward only
+    const bool pad = a.d != D || D == 256;   // padded head dims and the 256-wide tiles run the split backward only
     const long long rows = (long long)a.bh * a.n;
     float* dq_acc = reinterpret_cast<float*>(a.workspace);
     float* nlse = dq_acc + nel;
@@ -381,6 +381,7 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         return launch_bwd_dq_mfma(a, nlse, ndelta, st);
     }
+    if constexpr (D != 256) {
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * 32 * D * 2 + BK * 32 * 2 + 2 * 64 * sizeof(float);
     const float c = a.scale * 1.4426950408889634f;
@@ -406,10 +407,12 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(dq_convert_kernel<Tag>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st,
                            (const float*)dq_acc, (uint16_t*)a.dq, n8, a.scale);
     }
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st) {
+    if (a.d > 128) return a.dtype == 2 ? launch_bwd_t<bf16_tag, 256>(a, st) : launch_bwd_t<f16_tag, 256>(a, st);
     if (a.dtype == 2) return a.d > 64 ? launch_bwd_t<bf16_tag, 128>(a, st) : launch_bwd_t<bf16_tag, 64>(a, st);
     return a.d > 64 ? launch_bwd_t<f16_tag, 128>(a, st) : launch_bwd_t<f16_tag, 64>(a, st);
 }
