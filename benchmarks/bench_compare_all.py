@@ -5,7 +5,7 @@
     python benchmarks/bench_compare_all.py --seqlen 4096 --head-dim 128 --batch-size 8 --num-heads 32 --dtypes bf16
 
 "backward" = clones of q, k, v with requires_grad + forward + out.sum().backward(), timed together
-(bench_fa3.py:131-154).  Shapes the 16-bit MFMA kernels do not cover (d=256, fp32) run on the exact-f32 kernels.
+(bench_fa3.py:131-154).  fp32 tensors (and head dims that are not a multiple of 8) run on the exact-f32 kernels.
 """
 import argparse
 import sys

@@ -45,3 +45,20 @@ def test_make_qkv_is_the_seeded_generator_order():
     assert torch.equal(q, torch.randn((1, 2, 8, 4), generator=g)) and torch.equal(k, torch.randn((1, 2, 8, 4), generator=g))
     mean, std, mem = bu.benchmark_fn(lambda: q @ k.transpose(-1, -2), "cpu", 1, 3)
     assert mean > 0 and std >= 0 and mem is None
+
+
+def test_per_algorithm_entry_points_exist_and_refuse_to_run_without_a_gpu():
+    """benchmarks/bench_fa{1,2,3}.py mirror the reference's per-algorithm scripts; with no GPU they must exit loudly
+    (no CPU fallback), not print an empty table."""
+    import subprocess
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for a in (1, 2, 3):
+        path = os.path.join(root, "benchmarks", f"bench_fa{a}.py")
+        assert os.path.exists(path)
+        if not torch.cuda.is_available():
+            r = subprocess.run([sys.executable, path, "--seqlen", "128", "--no-save"], capture_output=True, text=True,
+                               cwd=os.path.join(root, "benchmarks"))
+            assert r.returncode != 0 and "no CPU backend" in (r.stderr + r.stdout)
