@@ -12,10 +12,11 @@
 //   dQ^T += K^T dS^T (A: K^T by ds_read_b64_tr_b16, B: dS^T straight from the accumulator registers)
 #include "fa_common.h"
 #include "fa_kernels.h"
+#include <type_traits>
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD>
+template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF>
 __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq
     const bool has_next = it + 1 < ntile_wg;
     const int kend = CAUSAL ? min(n, q0 + BM) : n;
     const int ntiles = (kend + BN - 1) / BN;
+    const float nl2 = nl * c_log2;   // -lse * log2(e): P = exp2(c S + nl2)
 #pragma unroll
     for (int t = 0; t < NDB; ++t)
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq
             for (int kb = 0; kb < 2; ++kb) {
                 f32x16 sacc, pacc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { sacc[i] = nl; pacc[i] = nd; }
+                for (int i = 0; i < 16; ++i) { sacc[i] = NLF ? 0.f : nl; pacc[i] = nd; }   // NLF: S starts at 0 (free), -lse rides the exp2 fma
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     const int off = TileSwz<D>::off(32 * kb + r, 2 * ks + h);
@@ -129,12 +131,12 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq
                 if (need_mask) {   // wave-uniform: only diagonal / ragged blocks pay for the compare + select
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                        const float p = __builtin_amdgcn_exp2f(NLF ? fmaf(sacc[i], c_log2, nl2) : sacc[i] * c_log2);
                         pacc[i] = ((i & 3) + 8 * (i >> 2) > thr) ? 0.f : p * pacc[i];
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) pacc[i] = __builtin_amdgcn_exp2f(sacc[i] * c_log2) * pacc[i];
+                    for (int i = 0; i < 16; ++i) pacc[i] = __builtin_amdgcn_exp2f(NLF ? fmaf(sacc[i], c_log2, nl2) : sacc[i] * c_log2) * pacc[i];
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -214,11 +216,23 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
                            a.scale, (int)a.d);
         return hipGetLastError();
     };
+    auto pick = [&](auto nlf) -> hipError_t {
+        constexpr bool NLF = decltype(nlf)::value;
     if constexpr (KT == 1 && D != 256) {
-        if (tpw == 2)
-            return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD>);
+            if (tpw == 2)
+                return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD, NLF>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD, NLF>);
+        }
+        return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1, PAD, NLF>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1, PAD, NLF>);
+    };
+    // option dq_nlf = 1: -lse enters through the exp2 fma and the S accumulators start at 0, instead of -lse/scale as
+    // the initial accumulator (16 v_mov per chain).  Measured a null at d = 128 and +1..3 % time at d = 64
+    // (profiles/r01_tile_sweep.md), so it is the default only for the 256-wide tiles, whose accumulators live in
+    // AGPRs (there the initial values are v_accvgpr_write's).
+    if constexpr (D == 256) return pick(std::true_type{});
+    if constexpr (KT == 1 && !PAD) {
+        if (option(OPT_DQ_NLF) == 1) return pick(std::true_type{});
     }
-    return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1, PAD>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1, PAD>);
+    return pick(std::false_type{});
 }
 
 // K/V tile of the dQ pass: 64 keys per barrier is the measured winner (2.98 vs 3.43 ms, profiles/r01_tile_sweep.md);

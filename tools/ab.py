@@ -13,11 +13,10 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("dkdv 1 key tile per workgroup", {"dkdv_tpw": 1}),
-    ("dkdv 2 key tiles per workgroup", {"dkdv_tpw": 2}),
+    ("dq: -lse through the exp2 fma", {"dq_nlf": 1}),
 
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf"]
 
 
 def main():
