@@ -16,8 +16,8 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF>
-__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF, bool W4>
+__global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ nlse,
@@ -25,7 +25,9 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq
                                                              int n, int nqt, float c_log2, float scale, int dr) {
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     // D = 256: 4 waves, one per SIMD, with the whole 512-register file each (Q, dO fragments 128 + dQ^T 128 registers)
-    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
+    // W4 (d <= 128): the same 4-wave shape but TWO workgroups per CU — the two waves of a SIMD then belong to different
+    // workgroups, share no barrier and drift out of phase (one in its MFMA phase, the other in its exp2 / pack phase)
+    constexpr int NW = (D == 256 || W4) ? 4 : 8, BM = 32 * NW, BN = 64 * KT, NKS = D / 16, NDB = D / 32;   // KT 64-key sub-tiles per LDS tile / barrier
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq
     }   // query tiles of this workgroup
 }
 
-template <typename Tag, int D, int KT, bool PAD = false>
+template <typename Tag, int D, int KT, bool PAD = false, bool W4 = false>
 static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW;
+    constexpr int NW = (D == 256 || W4) ? 4 : 8, BM = 32 * NW;
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = 2 * 2 * (64 * KT) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
@@ -220,9 +222,9 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
         constexpr bool NLF = decltype(nlf)::value;
     if constexpr (KT == 1 && D != 256) {
             if (tpw == 2)
-                return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD, NLF>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD, NLF>);
+                return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 2, PAD, NLF, W4>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 2, PAD, NLF, W4>);
         }
-        return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1, PAD, NLF>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1, PAD, NLF>);
+        return a.causal ? launch(bwd_dq_mfma_kernel<Tag, D, true, KT, 1, PAD, NLF, W4>) : launch(bwd_dq_mfma_kernel<Tag, D, false, KT, 1, PAD, NLF, W4>);
     };
     // option dq_nlf = 1: -lse enters through the exp2 fma and the S accumulators start at 0, instead of -lse/scale as
     // the initial accumulator (16 v_mov per chain).  Measured a null at d = 128 and +1..3 % time at d = 64
@@ -239,6 +241,7 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
 // option dq_kt=2 selects two 64-key sub-tiles per barrier (sweep)
 template <typename Tag, int D>
 static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    if (option(OPT_DQ_W4) == 1) return launch_dq_kt<Tag, D, 1, false, true>(a, nlse, ndelta, st);
     return option(OPT_DQ_KT) == 2 ? launch_dq_kt<Tag, D, 2>(a, nlse, ndelta, st) : launch_dq_kt<Tag, D, 1>(a, nlse, ndelta, st);
 }
 

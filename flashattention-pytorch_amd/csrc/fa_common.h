@@ -1,6 +1,8 @@
 // Shared device helpers for the gfx950 FlashAttention kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -142,6 +144,36 @@ typedef short lds_s16x4_t __attribute__((ext_vector_type(4)));
 // (lane i of the group gets column i of the 4 rows; lane 4q+p supplies the address of row q, columns 4p..4p+3).
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t __attribute__((address_space(3)))*)(p));
+}
+// the same reads from a 32-bit LDS byte address kept in a VGPR (lane-constant operand addresses are computed once and
+// advanced through the instruction's immediate offset; from generic pointers hipcc rebuilds every address separately)
+__device__ __forceinline__ s16x4 lds_tr16_at(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t __attribute__((address_space(3)))*)(uintptr_t)addr);
+}
+__device__ __forceinline__ s16x8 lds_b128_at(unsigned addr) {
+    return *(const s16x8 __attribute__((address_space(3)))*)(uintptr_t)addr;
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body
+template <typename F, int... Js>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, Js...>) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+// Hand-timed operand reads for the phases in which a wave is alone on its SIMD's matrix pipe: the read and its wait are
+// inline asm, so hipcc neither sinks the read to its use nor inserts waits of its own (it turns counted waits into
+// lgkmcnt(0) around ds_read_b64_tr_b16 pairs, which drains the prefetch every few MFMAs).  OFF = immediate byte offset.
+template <int OFF> __device__ __forceinline__ s16x4 lds_tr16_asm(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ s16x8 lds_b128_asm(unsigned addr) {
+    s16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// wait until at most N LDS operations issued after the ones that fill `x` are outstanding; ties x to the wait
+template <int N> __device__ __forceinline__ void lds_wait_for(s16x8& x) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
 }
 __device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 

@@ -20,10 +20,14 @@
 #include "fa_kernels.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD>
+// ABL != 0: ablation builds for profiling only (wrong results on purpose; option fwd_abl, tools/ab.py):
+//   bit 0: no exp2 / max / sum (P = S packed as is)   bit 1: no LDS-DMA, no barrier (every tile re-reads buffer 0)
+//   bit 2: no LDS operand reads (K and V^T fragments are register constants)
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD, int ABL = 0>
 __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
     const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
     for (int t = 0; t < ntiles_w; ++t) {
         const int k0 = t * BN;
-        const int cur = (gbase + t) & 1;
-        stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
+        const int cur = (ABL & 2) ? 0 : (gbase + t) & 1;
+        if (!(ABL & 2)) stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
 
         const char* Kt = smem + cur * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
                     for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
+                        const s16x8 a = (ABL & 4) ? qf[(ks + 1) % NKS] : *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
                         sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
                     }
                 }
@@ -179,11 +183,13 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
             }
             // ---- online softmax for query row `qrow` (per lane; the other 32 keys live in lane ^ 32)
             float mx = sacc[0][0];
+            if (!(ABL & 1)) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
             mx = fmaxf(mx, wave_half_swap(mx));
+            }
             // Online-softmax bookkeeping.  LAZY (default): keep the stale running max while no row of the wave has grown
             // past it by more than 2^8 (P then lies in (0, 256] instead of (0, 1]: the same relative precision in bf16 /
             // f16 / f32, no overflow), and skip the O / l rescale for that tile — it is needed in the first tiles only.
@@ -222,9 +228,9 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
             for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
+                    const float p = (ABL & 1) ? sacc[kb][i] : __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
                     sacc[kb][i] = p;
-                    if (!RS_MFMA) rs += p;
+                    if (!RS_MFMA && !(ABL & 1)) rs += p;
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
                         const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
                         const s16x4 lo = lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1));
                         const s16x4 hi = lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1));
-                        const s16x8 a = cat8(lo, hi);
+                        const s16x8 a = (ABL & 4) ? qf[dvb] : cat8(lo, hi);
                         oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
                     }
                 }
@@ -288,8 +294,10 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
             }
             l_run += rs;
         }
+        if (!(ABL & 2)) {
         dma_wait_all();   // this wave's share of the next tile has landed ...
         __syncthreads();  // ... and so has everyone else's
+        }
     }
     // causal: this wave's rows end before the workgroup's last tiles; keep feeding the other waves' tiles
     for (int t = ntiles_w; t < ntiles; ++t) {
@@ -326,6 +334,11 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mf
 bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 256 && d % 8 == 0; }
 
 // ------------------------------------------------------------------------------------------------
+// Debug trace (tools/trace_stag.py): when a buffer is registered, waves 0 and 4 of workgroup 0 of the staggered kernel
+// store the shader clock after every phase body and after every barrier.  [wave half][event] int64; event 0 = count.
+__device__ long long* g_trace = nullptr;
+hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
+
 // Staggered variant (FA_FWD_STAG=1; NOT the default: measured 2.58 ms vs 2.1-2.2 ms for the lock-step kernel at
 // B8 H32 N4096 d128, profiles/r01_tile_sweep.md).  The two waves that share a SIMD run the same program; with one barrier per tile they stay in
 // lock step, so their MFMA phases collide and their softmax (VALU) phases collide, and the tile time is the SUM of
@@ -339,12 +352,12 @@ template <typename Tag, int D, bool CAUSAL, int KB>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale, int /*dr: whole tile widths only*/) {
+                                                               float scale, int dbg /* debug ablation flags (option fwd_abl), 0 in production */) {
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | K2 | V0 | V1 | V2]: tile t in buffer t % 3
     char* Kbuf = smem;
-    char* Vbuf = smem + 2 * TILE_BYTES;
+    char* Vbuf = smem + 3 * TILE_BYTES;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = L / nqt;
@@ -369,9 +382,15 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
     const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w);
-    auto issue = [&](int u) {   // start of global half-step 2u
-        if (u + 1 < T) dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 1) & 1) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
-        if (u < T) dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (u & 1) * TILE_BYTES, u * BN, dma_voff, w);
+    // Issued at the start of global half-step 2u, first read in half-step 2u+4: K(u+2) and V(u+1).  Two tiles of
+    // flight time (a 64-key tile is consumed in about a microsecond, less than one trip to L2 / HBM under load).
+    // Always issued, so every wave has the same number of DMAs per step and the waits can be counted; tiles past the
+    // end of the tensor cost nothing (the range check answers with zeros).
+    constexpr int DMA_PER_ISSUE = 2 * (BN / (512 / D)) / 8;
+    auto issue = [&](int u) {
+        if (dbg & 4) return;                                   // ablation: no DMA
+        dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 2) % 3) * TILE_BYTES, (u + 2) * BN, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(v_rs, Vbuf + ((u + 1) % 3) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
     };
 
     f32x16 oacc[NDV];
@@ -384,20 +403,17 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     u32x4 pp[KB][2];
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
 
-    auto do_S = [&](int t) {
-        const char* Kt = Kbuf + (t & 1) * TILE_BYTES;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
-                sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
-            }
-        }
-    };
     auto do_softmax = [&](int t) {
+        if (dbg & 8) return;                                   // ablation: no V phase at all
+        if (dbg & 1) {                                         // ablation: pack only
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
+            return;
+        }
         const int k0 = t * BN;
         const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
         if (need_mask) {
@@ -417,10 +433,21 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
         mx = fmaxf(mx, wave_half_swap(mx));
         const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
-        const float mc = m_use * c_log2;
-        m_run = m_new;
+        float mc;
+        // lazy rescale, as in the lock-step kernel: O and l move to the new max only when some row grew by > 2^8
+        if (__any((m_new - m_run) * c_log2 > 8.0f) != 0) {
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
+            mc = m_use * c_log2;
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+        } else {
+            mc = m_run * c_log2;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -430,11 +457,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
                 sacc[kb][i] = p;
                 rs += p;
             }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int t2 = 0; t2 < NDV; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+        l_run += rs;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -442,49 +465,135 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
     };
-    auto do_PV = [&](int t) {
-        const char* Vt = Vbuf + (t & 1) * TILE_BYTES;
+    // lane-constant operand addresses (LDS bytes, buffer 0 of K / V); rows advance through the immediate offset: the
+    // swizzle depends on the row modulo 16 only, so +32 kb (+16 s) rows is a constant number of bytes
+    unsigned ka[NKS], vlo[NDV], vhi[NDV];
+    {
+        const unsigned k0a = lds_addr_of(Kbuf), v0a = lds_addr_of(Vbuf);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int ks = 0; ks < NKS; ++ks) ka[ks] = k0a + TileSwz<D>::off(r, 2 * ks + h);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[kb][s]);
-                const int key_a = 32 * kb + 16 * s + 4 * h + tq;
+        for (int dvb = 0; dvb < NDV; ++dvb) {
+            const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
+            vlo[dvb] = v0a + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
+            vhi[dvb] = v0a + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
+        }
+    }
+    auto do_M = [&](auto has_pv, auto has_s, int t) {
+        constexpr bool PV = decltype(has_pv)::value, SS = decltype(has_s)::value;
+        constexpr int NPV = PV ? KB * 2 * NDV : 0, NS = SS ? KB * NKS : 0, NSTEP = NPV + NS;
+        constexpr int ROWB = 2 * D;
+        // Step order: a lone wave needs several INDEPENDENT accumulation chains in flight — back-to-back MFMAs into one
+        // accumulator run at about half rate (tools/ubench/overlap.hip) — so P.V steps (NDV chains) and S steps (KB
+        // chains) alternate, and consecutive S steps alternate between the key blocks.
+        // step j -> (is_pv, index): P.V index p = (kb, s2, dvb) with dvb fastest; S index i = (ks, kb) with kb fastest.
+        struct Map {
+            static constexpr bool is_pv(int j) { return NS == 0 || (NPV != 0 && (j < 2 * (NPV < NS ? NPV : NS) ? (j & 1) == 0 : NPV > NS)); }
+            static constexpr int idx(int j) {
+                constexpr int m = NPV < NS ? NPV : NS;
+                return (NPV == 0 || NS == 0) ? j : (j < 2 * m ? j / 2 : j - m);
+            }
+        };
+        // this phase's buffers folded into the lane addresses once; everything else is an immediate offset
+        const unsigned vsel = (t % 3) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % 3) * TILE_BYTES;
+        unsigned kq[NKS], vl[NDV], vh[NDV];
 #pragma unroll
-                for (int dvb = 0; dvb < NDV; ++dvb) {
-                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
-                    const s16x8 a = cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
-                                         lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
-                    oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
+        for (int ks = 0; ks < NKS; ++ks) kq[ks] = ka[ks] + ksel;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb) { vl[dvb] = vlo[dvb] + vsel; vh[dvb] = vhi[dvb] + vsel; }
+        constexpr int RD = 4;   // ring slots: operands are requested RD - 1 MFMAs ahead
+        s16x8 ring[RD];
+        auto fetch = [&](auto jc) {   // operand fragment of step j into its ring slot
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < NSTEP) {
+                constexpr int x = Map::idx(j);
+                if constexpr (Map::is_pv(j)) {
+                    constexpr int kb = x / (2 * NDV), s2 = (x / NDV) & 1, dvb = x % NDV, off = (32 * kb + 16 * s2) * ROWB;
+                    ring[j % RD] = cat8(lds_tr16_asm<off>(vl[dvb]), lds_tr16_asm<off>(vh[dvb]));
+                } else {
+                    constexpr int kb = x % KB, ks = x / KB;
+                    ring[j % RD] = lds_b128_asm<32 * kb * ROWB>(kq[ks]);
                 }
             }
+        };
+        auto nops = [](int j) constexpr { return j >= NSTEP ? 0 : (Map::is_pv(j) ? 2 : 1); };   // LDS instructions of step j
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = Map::idx(j);
+            fetch(std::integral_constant<int, j + RD - 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int newer = [&]() constexpr { int c = 0; for (int q = 1; q < RD; ++q) c += nops(j + q); return c; }();
+#ifdef FA_STAG_NOWAIT   /* timing experiment only: wrong results */
+            lds_wait_for<15>(ring[j % RD]);
+#else
+            lds_wait_for<newer>(ring[j % RD]);
+#endif
+            if constexpr (Map::is_pv(j)) {
+                constexpr int kb = x / (2 * NDV), s2 = (x / NDV) & 1, dvb = x % NDV;
+                oacc[dvb] = mfma32<Tag>(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
+            } else {
+                constexpr int kb = x % KB, ks = x / KB;
+                if constexpr (ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                    sacc[kb] = mfma32<Tag>(ring[j % RD], qf[ks], z);
+                } else {
+                    sacc[kb] = mfma32<Tag>(ring[j % RD], qf[ks], sacc[kb]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts below are exact
+        for_each_const(fetch, std::make_integer_sequence<int, RD - 1>{});
+        for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
     };
 
-    // K(0), then global half-steps g = 0 .. 2T+1, one barrier after each; a wave's local step is g - stag
-    // A DMA issued at an even half-step 2u is first read in half-step 2u+2: it has to have landed by the barrier that
-    // ends the ODD half-step 2u+1, so that is where each wave waits for its own share (never in between).
-    auto end_half = [&](int gg) { if (gg & 1) dma_wait_all(); __syncthreads(); };
+    // K(0), K(1), V(0), then global half-steps g = 0 .. 2T+1, one barrier after each; a wave's local step is g - stag.
+    // What half-step 2u+2 reads was issued at 2u-2 or earlier: at the barrier that ends the ODD half-step 2u+1 each
+    // wave waits until only its newest issue (that of 2u) is still in flight.
+    long long* const trace = g_trace;
+    const bool tron = trace != nullptr && blockIdx.x == 0 && (w == 0 || w == 4);
+    int tri = 1;
+    auto stamp = [&]() {
+        if (tron) {
+            // inline asm: hipcc must not see a scalar-memory read in flight, or every LDS wait nearby becomes lgkmcnt(0)
+            unsigned long long c;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory");
+            if (lane == 0 && tri < 2040) trace[(w >> 2) * 2048 + tri] = (long long)c;
+            ++tri;
+        }
+    };
+    auto end_half = [&](int gg) {
+        stamp();
+        if (gg & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_ISSUE) : "memory");
+        __syncthreads();
+        stamp();
+    };
     dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w);
+    dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w);
+    dma_stage_tile<D, BN, 8>(v_rs, Vbuf, 0, dma_voff, w);
     dma_wait_all();
     __syncthreads();
     int g = 0;
     if (stag) { issue(0); end_half(0); g = 1; }               // second half idles through half-step 0
     if (!(g & 1)) issue(g >> 1);
-    do_S(0);                                                  // M_0
+    do_M(std::false_type{}, std::true_type{}, 0);             // M_0 = S(0)
     end_half(g); ++g;
     for (int t = 0; t < Tw; ++t) {
         if (!(g & 1)) issue(g >> 1);
         do_softmax(t);                                        // V_t
         end_half(g); ++g;
         if (!(g & 1)) issue(g >> 1);
-        do_PV(t);                                             // M_{t+1}
-        if (t + 1 < Tw) do_S(t + 1);
+        do_M(std::true_type{}, std::true_type{}, t);          // M_{t+1} = P.V(t) ; S(t+1)  (after the last tile S is unused:
+                                                              // one code path keeps the accumulators in place)
         end_half(g); ++g;
     }
     for (; g < 2 * T + 2; ++g) {                              // feed-only half-steps (causal tail, idle half)
         if (!(g & 1)) issue(g >> 1);
         end_half(g);
     }
+    dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
+    if (tron && lane == 0) trace[(w >> 2) * 2048] = tri;
 
     const float l_tot = l_run + wave_half_swap(l_run);
     if (qrow < n) {
@@ -515,9 +624,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* _
                                                                float scale, int /*dr: whole tile widths only*/) {
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | V0 | V1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | K2 | V0 | V1 | V2]: tile t in buffer t % 3
     char* Kbuf = smem;
-    char* Vbuf = smem + 2 * TILE_BYTES;
+    char* Vbuf = smem + 3 * TILE_BYTES;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = L / nqt;
@@ -717,19 +826,24 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     if (smem < (size_t)NW * 32 * D * 2) smem = (size_t)NW * 32 * D * 2;   // the epilogue stages the BM x D output tile in LDS
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
+    int dbg_flags = 0;   // staggered kernel only: its last argument carries debug ablation flags instead of the row length
     ProfScope ps(K_FWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, (int)a.d);
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, dbg_flags ? dbg_flags : (int)a.d);
         return hipGetLastError();
     };
     // experimental schedules (sweep evidence only): built for bf16, d = 128, 64-key tiles; anything else runs lock-step
     if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2 && !PAD) {
         const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
         if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
-        if (stag) return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
+        if (stag) {
+            smem = (size_t)6 * (32 * KB) * D * 2;   // K and V, three buffers each
+            dbg_flags = option(OPT_FWD_ABL);
+            return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
+        }
     }
     if constexpr (!PAD && D != 256) {   // sweep variants exist for the 64 / 128 tile widths only
     if (option(OPT_FWD_RS) != 0)
@@ -738,6 +852,17 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
         return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, false, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, false, false, 1, PAD>);
     if (option(OPT_FWD_HS) != 0)
         return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, true, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, true, 1, PAD>);
+    }
+    if constexpr (KB == 4 && D == 128 && !PAD && std::is_same<Tag, bf16_tag>::value) {
+        if (!a.causal) switch (option(OPT_FWD_ABL)) {   // profiling ablations: see the kernel's header comment
+            case 1: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 1>);
+            case 2: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 2>);
+            case 3: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 3>);
+            case 4: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 4>);
+            case 6: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 6>);
+            case 7: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 7>);
+            default: break;
+        }
     }
     if constexpr (KB == 4) {
         // query tiles per workgroup: measured winners (profiles/r01_tile_sweep.md) are 2 under the causal mask (heavy +

@@ -31,7 +31,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 EXPORTED_C_SYMBOLS = (
     "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
     "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
-    "fa_set_kernel_mode", "fa_set_option", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
+    "fa_set_kernel_mode", "fa_set_option", "fa_debug_trace_buffer", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
 )
 
 
@@ -65,6 +65,8 @@ def _load_library() -> ctypes.CDLL:
     lib.fa_version.restype = ctypes.c_char_p
     lib.fa_set_kernel_mode.argtypes = [ci]
     lib.fa_set_kernel_mode.restype = ci
+    lib.fa_debug_trace_buffer.argtypes = [vp]
+    lib.fa_debug_trace_buffer.restype = ci
     lib.fa_set_option.argtypes = [ctypes.c_char_p, ci]
     lib.fa_set_option.restype = ci
     lib.fa_device_is_gfx950.argtypes = [ci]
@@ -92,6 +94,11 @@ def set_kernel_mode(mode: int) -> int:
 def set_option(name: str, value: int) -> None:
     """Tuning knob for sweeps / A-B runs (fwd_kb, fwd_stag, fwd_pipe, dkdv); see csrc/fa_kernels.h."""
     _check(_lib.fa_set_option(name.encode(), int(value)))
+
+
+def debug_trace_buffer(t) -> None:
+    """Debug: register a CUDA int64 tensor of >= 4096 elements for the staggered forward's phase timestamps (None = off)."""
+    _check(_lib.fa_debug_trace_buffer(ctypes.c_void_p(t.data_ptr() if t is not None else 0)))
 
 
 def profile_enable(on: bool) -> None:

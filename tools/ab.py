@@ -13,10 +13,10 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("dq: -lse through the exp2 fma", {"dq_nlf": 1}),
-
+    ("fwd: staggered halves + pinned operand prefetch (64-key tiles)", {"fwd_stag": 1}),
+    ("fwd: lock-step 64-key tiles", {"fwd_kb": 2}),
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl"]
 
 
 def main():
