@@ -175,6 +175,22 @@ template <int OFF> __device__ __forceinline__ s16x8 lds_b128_asm(unsigned addr) 
 template <int N> __device__ __forceinline__ void lds_wait_for(s16x8& x) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
 }
+// wait + MFMA as ONE asm statement (no compiler-inserted s_nop between them, one issue slot less per step).  The
+// caller owns the hazards: nothing reads `c` by VALU within ~20 cycles (the users sit behind a barrier).
+#define FA_MFMA_WAIT_IMPL(TAG, OPC)                                                                                     \
+    template <int N> struct MfmaWait_##TAG {                                                                            \
+        static __device__ __forceinline__ void acc(s16x8 a, s16x8 b, f32x16& c) {                                       \
+            asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "n"(N));           \
+        }                                                                                                               \
+        static __device__ __forceinline__ void first(s16x8 a, s16x8 b, f32x16& c) {                                     \
+            asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b), "n"(N));            \
+        }                                                                                                               \
+    };
+FA_MFMA_WAIT_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
+FA_MFMA_WAIT_IMPL(f16, "v_mfma_f32_32x32x16_f16")
+template <typename Tag, int N> struct MfmaWait;
+template <int N> struct MfmaWait<bf16_tag, N> : MfmaWait_bf16<N> {};
+template <int N> struct MfmaWait<f16_tag, N> : MfmaWait_f16<N> {};
 __device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // ---- LDS-DMA staging of a swizzled tile -----------------------------------------------------------

@@ -522,24 +522,13 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             fetch(std::integral_constant<int, j + RD - 1>{});
             __builtin_amdgcn_sched_barrier(0);
             constexpr int newer = [&]() constexpr { int c = 0; for (int q = 1; q < RD; ++q) c += nops(j + q); return c; }();
-#ifdef FA_STAG_NOWAIT   /* timing experiment only: wrong results */
-            lds_wait_for<15>(ring[j % RD]);
-#else
-            lds_wait_for<newer>(ring[j % RD]);
-#endif
             if constexpr (Map::is_pv(j)) {
                 constexpr int kb = x / (2 * NDV), s2 = (x / NDV) & 1, dvb = x % NDV;
-                oacc[dvb] = mfma32<Tag>(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
+                MfmaWait<Tag, newer>::acc(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
             } else {
                 constexpr int kb = x % KB, ks = x / KB;
-                if constexpr (ks == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                    sacc[kb] = mfma32<Tag>(ring[j % RD], qf[ks], z);
-                } else {
-                    sacc[kb] = mfma32<Tag>(ring[j % RD], qf[ks], sacc[kb]);
-                }
+                if constexpr (ks == 0) MfmaWait<Tag, newer>::first(ring[j % RD], qf[ks], sacc[kb]);
+                else MfmaWait<Tag, newer>::acc(ring[j % RD], qf[ks], sacc[kb]);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
