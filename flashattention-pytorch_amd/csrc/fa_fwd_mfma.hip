@@ -405,6 +405,21 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
 
     auto do_softmax = [&](int t) {
         if (dbg & 8) return;                                   // ablation: no V phase at all
+        if (dbg & 32) {                                        // ablation: a plain exp2+fma chain of the same length, then pack
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[kb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], 0.5f, -1.0f));
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
+            return;
+        }
         if (dbg & 1) {                                         // ablation: pack only
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
@@ -479,7 +494,14 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             vhi[dvb] = v0a + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
         }
     }
-    auto do_M = [&](auto has_pv, auto has_s, int t) {
+    // The phase comes in two parts: WHICH = 0 (addresses of this phase's buffers + the first RD-1 operand requests) runs
+    // at the END of the preceding phase, ahead of the barrier, so the LDS latency of the first operands passes while the
+    // wave waits for its partner; WHICH = 1 is the MFMA stream.
+    constexpr int RD = 4;   // ring slots: operands are requested RD - 1 MFMAs ahead
+    s16x8 ring[RD];
+    unsigned kq[NKS], vl[NDV], vh[NDV];
+    auto do_M = [&](auto has_pv, auto has_s, auto which, int t) {
+        constexpr int WHICH = decltype(which)::value;
         constexpr bool PV = decltype(has_pv)::value, SS = decltype(has_s)::value;
         constexpr int NPV = PV ? KB * 2 * NDV : 0, NS = SS ? KB * NKS : 0, NSTEP = NPV + NS;
         constexpr int ROWB = 2 * D;
@@ -495,14 +517,13 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             }
         };
         // this phase's buffers folded into the lane addresses once; everything else is an immediate offset
-        const unsigned vsel = (t % 3) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % 3) * TILE_BYTES;
-        unsigned kq[NKS], vl[NDV], vh[NDV];
+        if constexpr (WHICH == 0) {
+            const unsigned vsel = (t % 3) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % 3) * TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kq[ks] = ka[ks] + ksel;
+            for (int ks = 0; ks < NKS; ++ks) kq[ks] = ka[ks] + ksel;
 #pragma unroll
-        for (int dvb = 0; dvb < NDV; ++dvb) { vl[dvb] = vlo[dvb] + vsel; vh[dvb] = vhi[dvb] + vsel; }
-        constexpr int RD = 4;   // ring slots: operands are requested RD - 1 MFMAs ahead
-        s16x8 ring[RD];
+            for (int dvb = 0; dvb < NDV; ++dvb) { vl[dvb] = vlo[dvb] + vsel; vh[dvb] = vhi[dvb] + vsel; }
+        }
         auto fetch = [&](auto jc) {   // operand fragment of step j into its ring slot
             constexpr int j = decltype(jc)::value;
             if constexpr (j < NSTEP) {
@@ -532,9 +553,15 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts below are exact
-        for_each_const(fetch, std::make_integer_sequence<int, RD - 1>{});
-        for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
+        if constexpr (WHICH == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts are exact
+            for_each_const(fetch, std::make_integer_sequence<int, RD - 1>{});
+        } else {
+            // the matrix-phase wave outranks its partner's vector phase (option fwd_hs = 1 turns this off for the A/B)
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);
+            for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+        }
     };
 
     // K(0), K(1), V(0), then global half-steps g = 0 .. 2T+1, one barrier after each; a wave's local step is g - stag.
@@ -566,14 +593,16 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     int g = 0;
     if (stag) { issue(0); end_half(0); g = 1; }               // second half idles through half-step 0
     if (!(g & 1)) issue(g >> 1);
-    do_M(std::false_type{}, std::true_type{}, 0);             // M_0 = S(0)
+    do_M(std::false_type{}, std::true_type{}, std::integral_constant<int, 0>{}, 0);
+    do_M(std::false_type{}, std::true_type{}, std::integral_constant<int, 1>{}, 0);             // M_0 = S(0)
     end_half(g); ++g;
     for (int t = 0; t < Tw; ++t) {
         if (!(g & 1)) issue(g >> 1);
         do_softmax(t);                                        // V_t
+        do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, t);   // first operands of M_{t+1}: both tiles landed a step ago
         end_half(g); ++g;
         if (!(g & 1)) issue(g >> 1);
-        do_M(std::true_type{}, std::true_type{}, t);          // M_{t+1} = P.V(t) ; S(t+1)  (after the last tile S is unused:
+        do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 1>{}, t);          // M_{t+1} = P.V(t) ; S(t+1)  (after the last tile S is unused:
                                                               // one code path keeps the accumulators in place)
         end_half(g); ++g;
     }
@@ -583,208 +612,6 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     }
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     if (tron && lane == 0) trace[(w >> 2) * 2048] = tri;
-
-    const float l_tot = l_run + wave_half_swap(l_run);
-    if (qrow < n) {
-        const float inv = 1.f / l_tot;
-        uint16_t* orow = o + base + (size_t)qrow * D;
-#pragma unroll
-        for (int dvb = 0; dvb < NDV; ++dvb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                u32x2 pk;
-                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
-                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
-            }
-        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined variant (FA_FWD_PIPE=1): S^T of tile t+1 (matrix pipe) is issued in the same basic block as the
-// online softmax of tile t (vector pipe), so one wave's instruction stream alternates MFMA and VALU work instead of
-// running them back to back; P.V of tile t follows.  K is prefetched two tiles ahead, V one (K and V each double
-// buffered), one barrier per tile.
-template <typename Tag, int D, bool CAUSAL, int KB>
-__global__ __launch_bounds__(512, 2) void fwd_mfma_pipe_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
-                                                               const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
-                                                               float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale, int /*dr: whole tile widths only*/) {
-    constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
-    constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | K2 | V0 | V1 | V2]: tile t in buffer t % 3
-    char* Kbuf = smem;
-    char* Vbuf = smem + 3 * TILE_BYTES;
-
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nqt;
-    int qt = L - bh * nqt;
-    if (CAUSAL) qt = nqt - 1 - qt;
-    const int q0 = qt * BM;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int qrow = q0 + 32 * w + r;
-    const size_t base = (size_t)bh * n * D;
-
-    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
-    s16x8 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
-
-    const int kend = CAUSAL ? min(n, q0 + BM) : n;
-    const int T = (kend + BN - 1) / BN;
-    const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31) / BN + 1) : T;
-
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
-    const int dma_voff = dma_lane_voff<D>(lane, w);
-    auto load_k = [&](int t) { if (t < T) dma_stage_tile<D, BN, 8>(k_rs, Kbuf + (t & 1) * TILE_BYTES, t * BN, dma_voff, w); };
-    auto load_v = [&](int t) { if (t < T) dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (t & 1) * TILE_BYTES, t * BN, dma_voff, w); };
-
-    f32x16 oacc[NDV];
-#pragma unroll
-    for (int t = 0; t < NDV; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
-
-    auto do_S = [&](int t, f32x16 (&sacc)[KB]) {
-        const char* Kt = Kbuf + (t & 1) * TILE_BYTES;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Kt + TileSwz<D>::off(32 * kb + r, 2 * ks + h));
-                sacc[kb] = mfma32<Tag>(a, qf[ks], sacc[kb]);
-            }
-        }
-    };
-    // softmax of tile t in place (sacc -> P), O rescale, packed P out
-    auto do_softmax = [&](int t, f32x16 (&sacc)[KB], u32x4 (&pp)[KB][2]) {
-        const int k0 = t * BN;
-        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
-        const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if ((i & 3) + 8 * (i >> 2) > thr) sacc[kb][i] = -INFINITY;
-                mx = fmaxf(mx, sacc[kb][i]);
-            }
-        }
-        mx = fmaxf(mx, wave_half_swap(mx));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * c_log2);
-        const float mc = m_use * c_log2;
-        m_run = m_new;
-        float rs = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c_log2, -mc));
-                sacc[kb][i] = p;
-                rs += p;
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
-        }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int t2 = 0; t2 < NDV; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
-    };
-    auto do_PV = [&](int t, u32x4 (&pp)[KB][2]) {
-        const char* Vt = Vbuf + (t & 1) * TILE_BYTES;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8 pb = *reinterpret_cast<s16x8*>(&pp[kb][s]);
-                const int key_a = 32 * kb + 16 * s + 4 * h + tq;
-#pragma unroll
-                for (int dvb = 0; dvb < NDV; ++dvb) {
-                    const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
-                    const s16x8 a = cat8(lds_tr16(Vt + TileSwz<D>::off(key_a, ch) + 8 * (tp & 1)),
-                                         lds_tr16(Vt + TileSwz<D>::off(key_a + 8, ch) + 8 * (tp & 1)));
-                    oacc[dvb] = mfma32<Tag>(a, pb, oacc[dvb]);
-                }
-            }
-    };
-
-    // Scheduling directive for the region that holds S(t+1) and softmax(t): one MFMA, its K fragment read, then a
-    // slice of the softmax VALU work, repeated — an in-order wave only overlaps its own MFMA and VALU work when they
-    // alternate in program order (hipcc otherwise emits all 8*KB MFMAs first, then the softmax).
-    auto interleave = [&]() {
-#pragma unroll
-        for (int i = 0; i < KB * NKS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            __builtin_amdgcn_sched_group_barrier(0x402, 16, 0);  // VALU + TRANS
-        }
-    };
-    load_k(0); load_k(1); load_v(0);
-    dma_wait_all();
-    __syncthreads();
-    f32x16 sa[KB], sb[KB];
-    u32x4 pp[KB][2];
-    do_S(0, sa);
-    // steady state: tiles come in pairs so that the two S buffers keep static names (no runtime-indexed registers)
-    int t = 0;
-    for (; t + 2 <= Tw - 1; t += 2) {
-        load_k(t + 2); load_v(t + 1);
-        do_S(t + 1, sb);            // matrix pipe ...
-        do_softmax(t, sa, pp);      // ... under the vector work of the previous tile
-        interleave();
-        do_PV(t, pp);
-        dma_wait_all();
-        __syncthreads();
-        load_k(t + 3); load_v(t + 2);
-        do_S(t + 2, sa);
-        do_softmax(t + 1, sb, pp);
-        interleave();
-        do_PV(t + 1, pp);
-        dma_wait_all();
-        __syncthreads();
-    }
-    // tail: one or two tiles left, `sa` holds S of tile t
-    if (t + 1 <= Tw - 1) {
-        load_k(t + 2); load_v(t + 1);
-        do_S(t + 1, sb);
-        do_softmax(t, sa, pp);
-        interleave();
-        do_PV(t, pp);
-        dma_wait_all();
-        __syncthreads();
-        load_k(t + 3); load_v(t + 2);
-        do_softmax(t + 1, sb, pp);
-        do_PV(t + 1, pp);
-        dma_wait_all();
-        __syncthreads();
-        t += 2;
-    } else {
-        load_k(t + 2); load_v(t + 1);
-        do_softmax(t, sa, pp);
-        do_PV(t, pp);
-        dma_wait_all();
-        __syncthreads();
-        t += 1;
-    }
-    for (; t < T; ++t) {   // causal: keep feeding the tiles the other waves still need
-        load_k(t + 2); load_v(t + 1);
-        dma_wait_all();
-        __syncthreads();
-    }
 
     const float l_tot = l_run + wave_half_swap(l_run);
     if (qrow < n) {
@@ -826,8 +653,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     };
     // experimental schedules (sweep evidence only): built for bf16, d = 128, 64-key tiles; anything else runs lock-step
     if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2 && !PAD) {
-        const int stag = option(OPT_FWD_STAG), pipe = option(OPT_FWD_PIPE);
-        if (pipe) return a.causal ? launch(fwd_mfma_pipe_kernel<Tag, D, true, KB>) : launch(fwd_mfma_pipe_kernel<Tag, D, false, KB>);
+        const int stag = option(OPT_FWD_STAG);
         if (stag) {
             smem = (size_t)6 * (32 * KB) * D * 2;   // K and V, three buffers each
             dbg_flags = option(OPT_FWD_ABL);
@@ -876,7 +702,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
-    const bool experimental = option(OPT_FWD_STAG) != 0 || option(OPT_FWD_PIPE) != 0;
+    const bool experimental = option(OPT_FWD_STAG) != 0;
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2 || experimental) return launch_fwd_t<Tag, D, 2>(a, st);   // the experimental schedules use 64-key tiles
     return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key (LDS 128 KiB at d = 128)

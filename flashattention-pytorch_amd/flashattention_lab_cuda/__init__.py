@@ -92,7 +92,7 @@ def set_kernel_mode(mode: int) -> int:
 
 
 def set_option(name: str, value: int) -> None:
-    """Tuning knob for sweeps / A-B runs (fwd_kb, fwd_stag, fwd_pipe, dkdv); see csrc/fa_kernels.h."""
+    """Tuning knob for sweeps / A-B runs (fwd_kb, fwd_stag, fwd_tpw, dq_tpw, dkdv_tpw, ...); see csrc/fa_kernels.h."""
     _check(_lib.fa_set_option(name.encode(), int(value)))
 
 

@@ -104,7 +104,7 @@ const char* fa_version(void);
 int fa_set_kernel_mode(int mode);      /* FA_MODE_*; returns the previous mode */
 /* debug only: device buffer of 4096 int64 for the phase timestamps of the staggered forward kernel (NULL = off) */
 int fa_debug_trace_buffer(void* device_ptr);
-int fa_set_option(const char* name, int value); /* tuning knobs for sweeps: fwd_kb, fwd_stag, fwd_pipe, dkdv */
+int fa_set_option(const char* name, int value); /* tuning knobs for sweeps: fwd_kb, fwd_stag, fwd_tpw, dq_tpw, dkdv_tpw, ... (csrc/fa_kernels.h) */
 int fa_device_is_gfx950(int device);   /* 1 if `device` reports gcnArchName gfx950, 0 otherwise, <0 on HIP error */
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figure).
  * fa_profile_enable(1) starts collecting (and clears old records), fa_profile_report waits for the events and

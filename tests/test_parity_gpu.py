@@ -279,6 +279,36 @@ def test_backward_variants_agree_and_split_is_deterministic(causal, d, device):
         torch.testing.assert_close(x.cpu(), y, rtol=5e-2, atol=5e-2)
 
 
+FWD_OPTIONS = [
+    {"fwd_stag": 1}, {"fwd_kb": 2}, {"fwd_kb": 1}, {"fwd_tpw": 1}, {"fwd_tpw": 2}, {"fwd_eager": 1},
+    {"fwd_hs": 1}, {"dq_tpw": 1}, {"dq_tpw": 2}, {"dkdv_tpw": 1}, {"dkdv_tpw": 2}, {"dq_nlf": 1}, {"dq_w4": 1}, {"dq_kt": 2},
+    {"dkdv": 4},
+]
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("opts", FWD_OPTIONS, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_every_selectable_kernel_variant_matches_the_oracle(opts, causal, device):
+    """Each schedule / tiling kept in the library for the sweeps (fa_set_option) computes the same function: forward and
+    backward at d=128 bf16, several tiles deep, ragged N, against the fp64 oracle at the reference's bf16 bar."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = make_qkv(2, 1100, 128, torch.bfloat16, seed=77)
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, 128 ** -0.5, math_dtype=torch.float64)
+    for name, val in opts.items():
+        ext.set_option(name, val)
+    try:
+        o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, 128 ** -0.5, do=do.to(device))
+    finally:
+        for name in opts:
+            ext.set_option(name, 0)
+    tol = dtype_tolerances(torch.bfloat16)
+    torch.testing.assert_close(o.cpu(), ro, **tol)
+    torch.testing.assert_close(lse.cpu(), rlse, rtol=1e-3, atol=1e-3)
+    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
+        torch.testing.assert_close(a.cpu(), b, **tol)
+
+
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fa3_fp8_forward_and_backward(causal, dtype, device):

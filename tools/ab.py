@@ -16,7 +16,7 @@ VARIANTS = [
     ("fwd: staggered halves + pinned operand prefetch (64-key tiles)", {"fwd_stag": 1}),
     ("fwd: lock-step 64-key tiles", {"fwd_kb": 2}),
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "fwd_pipe", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl"]
 
 
 def main():

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void kp(float* out, int iters) {
 // Ping-pong: waves 0-3 and 4-7 alternate a matrix phase (64 LDS-fed MFMAs = one forward tile: S then P.V patterns) and
 // a vector phase (NV exp2+fma pairs = the tile's softmax), one s_barrier per phase when SYNC, free running otherwise.
 // LOCK: both halves run the same phase at the same time (what a lock-step kernel does).
-template <int NV, bool SYNC, bool LOCK, bool PF = false, int NSTEP = 64, bool VARB = false>
+template <int NV, bool SYNC, bool LOCK, bool PF = false, int NSTEP = 64, bool VARB = false, int PRIO = 0>
 __global__ __launch_bounds__(512, 2) void kpp(float* out, int iters, int roff = 0) {
     __shared__ __attribute__((aligned(16))) char tile[65536];
     for (int i = threadIdx.x; i < 65536 / 4; i += 512) reinterpret_cast<int*>(tile)[i] = 0x3c003c00 + (i & 1023);
@@ -170,7 +170,9 @@ __global__ __launch_bounds__(512, 2) void kpp(float* out, int iters, int roff = 
     for (int i = 0; i < 16; ++i) x[i] = 1.0f + i + threadIdx.x * 1e-3f;
     const int half = LOCK ? 0 : (w >= 4);
     if (VARB) { Kt += roff; Vt += roff; }   // runtime tile offset: addresses need a v_add per read
+    unsigned long long mcyc = 0, vcyc = 0, t0 = 0, t1 = 0;
     for (int ph = 0; ph < 2 * iters; ++ph) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
         if (((ph + half) & 1) == 0) {
           if (PF) {   // operand fragments two MFMAs ahead, order pinned
             auto kfrag = [&](int j) { return *reinterpret_cast<const s16x8*>(Kt + swz128(32 * (j >> 3) + r, 2 * (j & 7) + h)); };
@@ -214,28 +216,40 @@ __global__ __launch_bounds__(512, 2) void kpp(float* out, int iters, int roff = 
                     }
           }
         } else {
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(3);   // vector phase outranks the partner's matrix phase
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) x[v & 15] = __builtin_amdgcn_exp2f(fmaf(x[v & 15], 0.5f, -1.0f));
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(3);   // reverse: matrix phase outranks
         }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        if (((ph + half) & 1) == 0) mcyc += t1 - t0; else vcyc += t1 - t0;
         if (SYNC) __syncthreads();
     }
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += x[i] + c[0][i] + c[1][i] + c[2][i] + c[3][i];
     if (s == 12345.678f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) {
+        out[16 + 4 * (threadIdx.x >> 8)] = (float)((double)mcyc / iters);
+        out[17 + 4 * (threadIdx.x >> 8)] = (float)((double)vcyc / iters);
+    }
 }
-template <int NV, bool SYNC, bool LOCK, bool PF = false, int NSTEP = 64, bool VARB = false>
+template <int NV, bool SYNC, bool LOCK, bool PF = false, int NSTEP = 64, bool VARB = false, int PRIO = 0>
 static void runpp(const char* what, float* d, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((kpp<NV, SYNC, LOCK, PF, NSTEP, VARB>), dim3(256), dim3(512), 0, 0, d, 10, 0);
+    hipLaunchKernelGGL((kpp<NV, SYNC, LOCK, PF, NSTEP, VARB, PRIO>), dim3(256), dim3(512), 0, 0, d, 10, 0);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((kpp<NV, SYNC, LOCK, PF, NSTEP, VARB>), dim3(256), dim3(512), 0, 0, d, iters, 0);
+    hipLaunchKernelGGL((kpp<NV, SYNC, LOCK, PF, NSTEP, VARB, PRIO>), dim3(256), dim3(512), 0, 0, d, iters, 0);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("ping-pong NV=%d sync=%d lock=%d  %-44s %8.3f ms  (%.1f ns per MFMA per SIMD; MFMA-only floor 14.8)\n", NV, SYNC, LOCK, what,
-           ms, ms * 1e6 / iters / (2 * NSTEP));
+    float hc[8];
+    hipMemcpy(hc, d + 16, sizeof(hc), hipMemcpyDeviceToHost);
+    printf("ping-pong NV=%d sync=%d lock=%d  %-44s %8.3f ms  (%.1f ns per MFMA per SIMD; floor 14.8)  shader clocks per phase: wave0 M %.0f V %.0f | wave4 M %.0f V %.0f\n",
+           NV, SYNC, LOCK, what, ms, ms * 1e6 / iters / (2 * NSTEP), hc[0], hc[1], hc[4], hc[5]);
 }
 
 template <int PAT>
@@ -306,6 +320,11 @@ int main() {
     runpp<32, true, false, true, 32, true>("same + rotating B operands + runtime tile offset", d, iters / 4);
     runpp<0, true, false, true, 32, true>("same, empty V phase", d, iters / 4);
     runpp<64, true, false, true, 32>("32 MFMA | 64 pairs per phase, alternating + prefetch", d, iters / 4);
+    runpp<64, true, false, true, 32, true, 0>("32 MFMA | 64 pairs, alternating + prefetch, equal priority", d, iters / 4);
+    runpp<64, true, false, true, 32, true, 1>("same, vector phase at s_setprio 3", d, iters / 4);
+    runpp<64, true, false, true, 32, true, 2>("same, matrix phase at s_setprio 3", d, iters / 4);
+    runpp<96, true, false, true, 32, true, 0>("32 MFMA | 96 pairs, equal priority", d, iters / 4);
+    runpp<96, true, false, true, 32, true, 1>("32 MFMA | 96 pairs, vector phase at s_setprio 3", d, iters / 4);
     runpp<96, true, false>("96 exp2+fma per tile, alternating, barrier", d, iters / 4);
     runpp<96, true, true>("96 exp2+fma per tile, lock-step", d, iters / 4);
     return 0;
