@@ -15,8 +15,8 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD>
-__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD, bool W4 = false>
+__global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ nlse,
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dk
                                                                uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
                                                                float scale, int dr) {
     // D = 256: 4 waves (one per SIMD, 512 registers: dK^T and dV^T alone are 256), 128 keys, query tiles of 32 rows
-    constexpr int NW = D == 256 ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64, NKS = D / 16, NDB = D / 32;
+    // W4 (d <= 128): 4 waves = 128 keys per workgroup for launches too small to fill the CUs with 256-key tiles
+    constexpr int NW = (D == 256 || W4) ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64, NKS = D / 16, NDB = D / 32;
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int K_BYTES = BK * D * 2, Q_BYTES = BQ * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,15 +239,15 @@ __global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void bwd_dk
     }
 }
 
-template <typename Tag, int D, bool PAD = false>
+template <typename Tag, int D, bool PAD = false, bool W4 = false>
 static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    constexpr int NW = D == 256 ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64;
+    constexpr int NW = (D == 256 || W4) ? 4 : 8, BK = 32 * NW, BQ = D == 256 ? 32 : 64;
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * BQ * D * 2 + 2 * 128 * sizeof(float);
     const float c = a.scale * 1.4426950408889634f;
     // key tiles per workgroup: option dkdv_tpw (1 | 2), default see DESIGN.md
     int tpw = option(OPT_DKDV_TPW);
-    if (tpw == 0) tpw = a.causal ? 2 : 1;
+    if (tpw == 0) tpw = (a.causal && !W4) ? 2 : 1;   // small launches: as many workgroups as possible
     dim3 grid((unsigned)(((nkt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
@@ -257,13 +258,13 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
                            (int)a.n, nkt, c, a.scale, (int)a.d);
         return hipGetLastError();
     };
-    if constexpr (D == 64 && !PAD) {
+    if constexpr (D == 64 && !PAD && !W4) {
         if (option(OPT_DKDV_KREG) != 0)
-            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1, PAD>);
+            return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1, PAD, W4>);
     }
     if (tpw == 2)
-        return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2, PAD>);
-    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1, PAD>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1, PAD>);
+        return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2, PAD, W4>);
+    return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1, PAD, W4>);
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
@@ -274,6 +275,10 @@ hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float
     if (a.d != 64 && a.d != 128) {   // head dims below the tile width: zero-padded inside the kernel
         if (a.dtype == 2) return a.d > 64 ? launch_dkdv_t<bf16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, true>(a, nlse, ndelta, st);
         return a.d > 64 ? launch_dkdv_t<f16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, true>(a, nlse, ndelta, st);
+    }
+    if (option(OPT_DKDV_KREG) == 0 && option(OPT_DKDV_TPW) == 0 && small_grid(a.bh, a.n)) {   // 128-key tiles on 4 waves
+        if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, false, true>(a, nlse, ndelta, st);
+        return a.d == 128 ? launch_dkdv_t<f16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, false, true>(a, nlse, ndelta, st);
     }
     if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64>(a, nlse, ndelta, st);
     return a.d == 128 ? launch_dkdv_t<f16_tag, 128>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64>(a, nlse, ndelta, st);

@@ -241,7 +241,8 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
 // option dq_kt=2 selects two 64-key sub-tiles per barrier (sweep)
 template <typename Tag, int D>
 static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    if (option(OPT_DQ_W4) == 1) return launch_dq_kt<Tag, D, 1, false, true>(a, nlse, ndelta, st);
+    if (option(OPT_DQ_W4) == 1 || (option(OPT_DQ_W4) == 0 && option(OPT_DQ_KT) == 0 && option(OPT_DQ_TPW) == 0 && small_grid(a.bh, a.n)))
+        return launch_dq_kt<Tag, D, 1, false, true>(a, nlse, ndelta, st);
     return option(OPT_DQ_KT) == 2 ? launch_dq_kt<Tag, D, 2>(a, nlse, ndelta, st) : launch_dq_kt<Tag, D, 1>(a, nlse, ndelta, st);
 }
 

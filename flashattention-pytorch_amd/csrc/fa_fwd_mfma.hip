@@ -27,14 +27,16 @@ namespace fa {
 // ABL != 0: ablation builds for profiling only (wrong results on purpose; option fwd_abl, tools/ab.py):
 //   bit 0: no exp2 / max / sum (P = S packed as is)   bit 1: no LDS-DMA, no barrier (every tile re-reads buffer 0)
 //   bit 2: no LDS operand reads (K and V^T fragments are register constants)
-template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD, int ABL = 0>
-__global__ __launch_bounds__(D == 256 ? 256 : 512, D == 256 ? 1 : 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+// W4 (d <= 128): 4 waves = 128 query rows per workgroup, for launches whose 256-row tiles would leave CUs idle
+// (bh * ceil(N / 256) below the CU count): twice the workgroups, each with one wave per SIMD.
+template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD, int ABL = 0, bool W4 = false>
+__global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void fwd_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int n, int nqt, float c_log2,
                                                           float scale, int dr) {
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     // D = 256: 4 waves, one per SIMD, with the whole 512-register file each (Q fragments 64 + O^T 128 registers)
-    constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
+    constexpr int NW = (D == 256 || W4) ? 4 : 8, BM = 32 * NW, BN = 32 * KB, NKS = D / 16, NDV = D / 32;   // KB = 32-key blocks per K/V tile
     constexpr int TILE_BYTES = BN * D * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
 
@@ -699,6 +701,33 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 1, PAD>) : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD>);
 }
 
+// Small launches: 128-row tiles on 4 waves (W4)
+template <typename Tag, int D>
+static hipError_t launch_fwd_w4(const FwdArgs& a, hipStream_t st) {
+    constexpr int NW = 4, BM = 32 * NW, KB = 4;
+    const int nqt = (int)((a.n + BM - 1) / BM);
+    const size_t smem = 2 * 2 * (32 * KB) * D * 2;
+    const float c = a.scale * 1.4426950408889634f;
+    ProfScope ps(K_FWD_MFMA, st);
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nqt * a.bh)), dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, (int)a.d);
+        return hipGetLastError();
+    };
+    return a.causal ? launch(fwd_mfma_kernel<Tag, D, true, KB, false, true, false, 1, false, 0, true>)
+                    : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, false, 0, true>);
+}
+
+// does the launch leave CUs without a workgroup when tiled by 256 rows?  (option small_grid: 1 = never, 2 = always)
+bool small_grid(int64_t bh, int64_t n) {
+    const int o = option(OPT_SMALL_GRID);
+    if (o == 1) return false;
+    if (o == 2) return true;
+    return bh * ((n + 255) / 256) < 224;
+}
+
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
@@ -716,6 +745,12 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
     if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
+    }
+    const bool sweeping = option(OPT_FWD_KB) || option(OPT_FWD_STAG) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
+                          option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
+    if (!sweeping && small_grid(a.bh, a.n)) {
+        if (a.dtype == 2) return a.d == 128 ? launch_fwd_w4<bf16_tag, 128>(a, st) : launch_fwd_w4<bf16_tag, 64>(a, st);
+        return a.d == 128 ? launch_fwd_w4<f16_tag, 128>(a, st) : launch_fwd_w4<f16_tag, 64>(a, st);
     }
     if (a.dtype == 2) return a.d == 128 ? launch_fwd_kb<bf16_tag, 128>(a, st) : launch_fwd_kb<bf16_tag, 64>(a, st);
     return a.d == 128 ? launch_fwd_kb<f16_tag, 128>(a, st) : launch_fwd_kb<f16_tag, 64>(a, st);
