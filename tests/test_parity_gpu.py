@@ -65,11 +65,22 @@ SHAPES = [
 @pytest.mark.parametrize("bh,n,d", SHAPES)
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-def test_hip_matches_oracle_on_seeded_inputs(bh, n, d, causal, dtype, device):
+@pytest.mark.parametrize("tiles", ["8-wave", "4-wave"])
+def test_hip_matches_oracle_on_seeded_inputs(bh, n, d, causal, dtype, tiles, device):
+    """`tiles`: these shapes are small launches, which the library would give to its 4-wave / 128-row kernels
+    (csrc small_grid); both tilings are exercised on every shape (fp32 runs the exact-f32 kernels either way)."""
+    import flashattention_lab_cuda as ext
+
+    if dtype == torch.float32 and tiles == "4-wave":
+        pytest.skip("exact-f32 kernels have one tiling")
     q, k, v, do = make_qkv(bh, n, d, dtype, seed=1000 + n + d)
     scale = d ** -0.5
     rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, scale, math_dtype=torch.float64)
-    o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
+    ext.set_option("small_grid", 1 if tiles == "8-wave" else 2)
+    try:
+        o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
+    finally:
+        ext.set_option("small_grid", 0)
     tol = dtype_tolerances(dtype)
     torch.testing.assert_close(o.cpu(), ro, **tol)
     torch.testing.assert_close(lse.cpu(), rlse, rtol=1e-3, atol=1e-3)
