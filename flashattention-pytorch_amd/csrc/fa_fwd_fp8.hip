@@ -5,7 +5,7 @@
 // What it replaces: the fp8 branch of csrc/fa3/fa3_fwd.cu:196-208 (= src/fa3/torch/impl.py:118-133): per-block absmax
 // scales (block_absmax_scale, :70-85, eps 1e-6) and a quantise step.  The reference's quantise is an fp16 round trip
 // that models no 8-bit rounding, and its "Hadamard" rotation is not orthogonal; this implements the
-// intent — real e4m3 with block scales, no rotation — and is held to the reference's fp8 bar (1e-1,
+// intent — an orthogonal sign + Hadamard rotation, then real e4m3 with block scales — and is held to the reference's fp8 bar (1e-1,
 // tests/test_correctness_fa3.py:31-32) against the oracle's e4m3 model (oracle.fp8_attention) and the exact result.
 //
 // Two launches: fp8_quant_kernel (q and k -> e4m3 bytes + scales in the caller's workspace), fwd_fp8_kernel.
@@ -23,7 +23,33 @@ constexpr float kE4M3Max = 448.f;
 // OUT16 = false: write e4m3 bytes + scales (forward).  OUT16 = true: write the DEQUANTISED values back as 16-bit
 // tensors (backward: the gradient is taken of the function the forward actually evaluated, i.e. with the
 // quantised Q and K, which is also what the reference's fa3_backward does, csrc/fa3/fa3_bwd.cu:134-146).
-template <typename Tag, int D, bool OUT16>
+// ROT: incoherent processing first — every row x of Q and K becomes x . diag(s) . H / sqrt(D) (s a fixed +-1 vector,
+// H the Sylvester Hadamard matrix), the rotation the reference's FA3 path intends (src/fa3/torch/impl.py:20-45, SURVEY
+// D6).  It is orthogonal, so S = Q K^T is unchanged, and it spreads an outlier channel over all D channels so that one
+// e4m3 scale per 64-row block wastes no range on it.  A row lives in 16 consecutive lanes (8 elements each): three
+// butterfly stages in registers, four across the lanes.  OUT16 writes the round-tripped values back in the ORIGINAL
+// basis (H, then the signs: the rotation's transpose).
+__device__ __forceinline__ float rot_sign(int e) {
+    const unsigned h = ((unsigned)e * 0x9E3779B1u) >> 27;
+    return ((0x5A3C96E1u >> h) & 1u) ? -1.f : 1.f;
+}
+template <int D>
+__device__ __forceinline__ void hadamard_row(float (&x)[8], int ch) {   // ch = this lane's 8-element chunk of the row
+#pragma unroll
+    for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!(j & st)) { const float a = x[j], b = x[j | st]; x[j] = a + b; x[j | st] = a - b; }
+#pragma unroll
+    for (int bit = 1; bit < D / 8; bit <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float other = __shfl_xor(x[j], bit, 64);
+            x[j] = (ch & bit) ? other - x[j] : x[j] + other;
+        }
+}
+
+template <typename Tag, int D, bool OUT16, bool ROT>
 __global__ __launch_bounds__(256) void fp8_quant_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         uint8_t* __restrict__ q8, uint8_t* __restrict__ k8,
                                                         float* __restrict__ sq, float* __restrict__ sk, int n, int nb) {
@@ -34,15 +60,26 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const uint16_t* __restri
     float* sc = blockIdx.z == 0 ? sq : sk;
     const int bh = blockIdx.y, blk = blockIdx.x, row0 = blk * 64;
     const size_t base = (size_t)bh * n * D;
-    u32x4 x[PER];
+    float xf[PER][8];
     float amax = 0.f;
+    const float rs = 0.08838834764831845f * (D == 128 ? 1.f : 0.f);   // 1 / sqrt(128); the fp8 path is built for D = 128
+    static_assert(D == 128, "fp8 path: head_dim 128");
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = threadIdx.x + 256 * i, row = row0 + c / CPR, ch = c % CPR;
-        x[i] = u32x4{0u, 0u, 0u, 0u};
-        if (row < n) x[i] = *reinterpret_cast<const u32x4*>(src + base + (size_t)row * D + 8 * ch);
+        u32x4 x = u32x4{0u, 0u, 0u, 0u};
+        if (row < n) x = *reinterpret_cast<const u32x4*>(src + base + (size_t)row * D + 8 * ch);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(unpack_lo<Tag>(x[i][j])), fabsf(unpack_hi<Tag>(x[i][j]))));
+        for (int j = 0; j < 4; ++j) { xf[i][2 * j] = unpack_lo<Tag>(x[j]); xf[i][2 * j + 1] = unpack_hi<Tag>(x[j]); }
+        if (ROT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[i][j] *= rot_sign(8 * ch + j);
+            hadamard_row<D>(xf[i], ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[i][j] *= rs;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(xf[i][j]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -56,24 +93,31 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const uint16_t* __restri
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = threadIdx.x + 256 * i, row = row0 + c / CPR, ch = c % CPR;
-        if (row >= n) continue;
         int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][0]) * inv, unpack_hi<Tag>(x[i][0]) * inv, w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][1]) * inv, unpack_hi<Tag>(x[i][1]) * inv, w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][2]) * inv, unpack_hi<Tag>(x[i][2]) * inv, w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(unpack_lo<Tag>(x[i][3]) * inv, unpack_hi<Tag>(x[i][3]) * inv, w1, true);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][0] * inv, xf[i][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][2] * inv, xf[i][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][4] * inv, xf[i][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][6] * inv, xf[i][7] * inv, w1, true);
         if (!OUT16) {
+            if (row >= n) continue;
             u32x2 o2 = {(unsigned)w0, (unsigned)w1};
             *reinterpret_cast<u32x2*>(dst + base + (size_t)row * D + 8 * ch) = o2;
         } else {
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            u32x4 o4;
             const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
             const f32x2_t a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
-            o4[0] = pack2_rn<Tag>(a0[0] * scl, a0[1] * scl);
-            o4[1] = pack2_rn<Tag>(a1[0] * scl, a1[1] * scl);
-            o4[2] = pack2_rn<Tag>(a2[0] * scl, a2[1] * scl);
-            o4[3] = pack2_rn<Tag>(a3[0] * scl, a3[1] * scl);
+            float y[8] = {a0[0] * scl, a0[1] * scl, a1[0] * scl, a1[1] * scl, a2[0] * scl, a2[1] * scl, a3[0] * scl, a3[1] * scl};
+            if (ROT) {   // back to the original basis (every lane takes part in the shuffles, rows past n included)
+                hadamard_row<D>(y, ch);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] *= rs * rot_sign(8 * ch + j);
+            }
+            if (row >= n) continue;
+            u32x4 o4;
+            o4[0] = pack2_rn<Tag>(y[0], y[1]);
+            o4[1] = pack2_rn<Tag>(y[2], y[3]);
+            o4[2] = pack2_rn<Tag>(y[4], y[5]);
+            o4[3] = pack2_rn<Tag>(y[6], y[7]);
             *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dst) + base + (size_t)row * D + 8 * ch) = o4;
         }
     }
@@ -248,8 +292,12 @@ static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
     float* sk = sq + (size_t)a.bh * nb;
     {
         ProfScope ps(K_FP8_QUANT, st);
-        hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
-                           (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
+        if (option(OPT_FP8_ROT) == 2)   // option fp8_rot = 2: quantise without the incoherent rotation (A/B, tests)
+            hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false, false>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
+                               (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
+        else
+            hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false, true>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
+                               (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -273,14 +321,13 @@ hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt
                                 hipStream_t st) {
     const int nb = (int)((n + 63) / 64);
     ProfScope ps(K_FP8_QUANT, st);
-    if (dtype == 2)
-        hipLaunchKernelGGL((fp8_quant_kernel<bf16_tag, 128, true>), dim3(nb, (unsigned)bh, 2), dim3(256), 0, st,
-                           (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt, (uint8_t*)kt, (float*)nullptr,
-                           (float*)nullptr, (int)n, nb);
-    else
-        hipLaunchKernelGGL((fp8_quant_kernel<f16_tag, 128, true>), dim3(nb, (unsigned)bh, 2), dim3(256), 0, st,
-                           (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt, (uint8_t*)kt, (float*)nullptr,
-                           (float*)nullptr, (int)n, nb);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nb, (unsigned)bh, 2), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt,
+                           (uint8_t*)kt, (float*)nullptr, (float*)nullptr, (int)n, nb);
+    };
+    const bool rot = option(OPT_FP8_ROT) != 2;
+    if (dtype == 2) { if (rot) go(fp8_quant_kernel<bf16_tag, 128, true, true>); else go(fp8_quant_kernel<bf16_tag, 128, true, false>); }
+    else { if (rot) go(fp8_quant_kernel<f16_tag, 128, true, true>); else go(fp8_quant_kernel<f16_tag, 128, true, false>); }
     return hipGetLastError();
 }
 

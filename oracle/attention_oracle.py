@@ -45,6 +45,8 @@ from __future__ import annotations
 import math
 from typing import Optional, Tuple
 
+import numpy as np
+
 import torch
 
 __all__ = [
@@ -242,11 +244,39 @@ def quantize_e4m3_blockwise(x: torch.Tensor, block: int):
     return xq, scale
 
 
-def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k):
+def incoherent_signs(d: int) -> torch.Tensor:
+    """The fixed +-1 vector of the rotation below: sign(e) = bit (0x9E3779B1 * e mod 2^32) >> 27 of 0x5A3C96E1."""
+    e = np.arange(d, dtype=np.uint64)
+    h = ((e * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(27)
+    bit = (np.uint64(0x5A3C96E1) >> h) & np.uint64(1)
+    return torch.from_numpy(1.0 - 2.0 * bit.astype(np.float64)).float()
+
+
+def incoherent_rotate(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """x -> x . diag(s) . H / sqrt(d): the incoherent processing the reference's FA3 path intends before quantising Q
+    and K (`src/fa3/torch/impl.py:20-45`: random signs, then a Hadamard transform; its own transform is not orthogonal,
+    SURVEY D6).  Orthogonal, so (Q R)(K R)^T = Q K^T; it spreads an outlier channel over all d channels, which is what
+    makes one e4m3 scale per row block adequate.  H = Sylvester Hadamard matrix (d a power of two), fp32 arithmetic."""
+    d = x.shape[-1]
+    assert d & (d - 1) == 0, "Hadamard rotation needs a power-of-two head dim"
+    h = torch.ones(1, 1)
+    while h.shape[0] < d:
+        h = torch.cat([torch.cat([h, h], 1), torch.cat([h, -h], 1)], 0)
+    s = incoherent_signs(d)
+    xf = x.float()
+    if inverse:
+        return (xf @ h) * s / math.sqrt(d)
+    return ((xf * s) @ h) / math.sqrt(d)
+
+
+def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k, rotate: bool = True):
     """Attention with Q and K quantised to e4m3 per row block, V and P kept in 16/32-bit.
 
-    This is the numerical model of the HIP `fa3_forward(fp8=True)` path.
+    This is the numerical model of the HIP `fa3_forward(fp8=True)` path: Q and K are first rotated by
+    `incoherent_rotate` (rotate=False: the library's option fp8_rot=2), then quantised.
     """
+    if rotate:
+        q, k = incoherent_rotate(q), incoherent_rotate(k)
     qq, sq = quantize_e4m3_blockwise(q, block_q)
     kq, sk = quantize_e4m3_blockwise(k, block_k)
     n = q.shape[1]
@@ -255,7 +285,7 @@ def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k):
     qd = qq * rq[..., None]
     kd = kq * rk[..., None]
     o, lse = exact_attention(qd, kd, v.float(), causal, softmax_scale)
-    return o.to(q.dtype), lse
+    return o.to(v.dtype), lse
 
 
 # --------------------------------------------------------------------------- FLOP accounting

@@ -341,6 +341,36 @@ def test_fa3_fp8_forward_and_backward(causal, dtype, device):
         torch.testing.assert_close(a.cpu().float(), b.float(), rtol=1e-1, atol=1e-1)
 
 
+@pytest.mark.parametrize("rot", [0, 2], ids=["rotated", "plain"])
+def test_fa3_fp8_incoherent_rotation_against_its_model(rot, device):
+    """The sign + Hadamard rotation ahead of the e4m3 quantisation (option fp8_rot: 0 = on, 2 = off): each setting must
+    match the oracle's model of it, and with an outlier channel in Q and K the rotated path must be the more accurate."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 2, 400, 128
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=41)
+    q[..., 7] *= 30.0
+    k[..., 7] *= 30.0
+    scale = d ** -0.5
+    ext.set_option("fp8_rot", rot)
+    try:
+        o, lse, dq, dk, dv = _run(3, q.to(device), k.to(device), v.to(device), False, scale, do=do.to(device), fp8=True)
+    finally:
+        ext.set_option("fp8_rot", 0)
+    mo, mlse = orc.fp8_attention(q, k, v, False, scale, 64, 64, rotate=(rot == 0))
+    torch.testing.assert_close(o.cpu().float(), mo.float(), rtol=3e-2, atol=3e-2)
+    ro, _ = orc.exact_attention(q.double(), k.double(), v.double(), False, scale)
+    err = (o.cpu().double() - ro).abs().max().item()
+    test_fa3_fp8_incoherent_rotation_against_its_model.err[rot] = err
+    assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
+    if len(test_fa3_fp8_incoherent_rotation_against_its_model.err) == 2:
+        e = test_fa3_fp8_incoherent_rotation_against_its_model.err
+        assert e[0] < e[2], f"rotation did not help: {e}"
+
+
+test_fa3_fp8_incoherent_rotation_against_its_model.err = {}
+
+
 def test_fa3_fp8_flag_on_shapes_without_an_fp8_kernel_takes_the_regular_path(device):
     # the reference's own fp8 test shape: (1,2,32,32) fp16 — tests/test_correctness_fa3.py:74
     q, k, v, do = (t.to(device) for t in make_qkv(2, 32, 32, torch.float16, seed=22))
