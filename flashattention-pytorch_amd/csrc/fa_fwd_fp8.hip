@@ -1,5 +1,5 @@
 // FA3-style fp8 forward for gfx950: Q and K quantised to OCP e4m3 with one scale per (b,h, 64-row block),
-// S = Q K^T on v_mfma_f32_32x32x16_fp8_fp8, softmax / P / V / O exactly as the 16-bit forward (P and V stay 16 bit,
+// S = Q K^T on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands, unit hardware scales; 2x the bf16 rate), softmax / P / V / O exactly as the 16-bit forward (P and V stay 16 bit,
 // fp32 accumulation).  head_dim 128, f16 / bf16 tensors.
 //
 // What it replaces: the fp8 branch of csrc/fa3/fa3_fwd.cu:196-208 (= src/fa3/torch/impl.py:118-133): per-block absmax
@@ -10,8 +10,8 @@
 //
 // Two launches: fp8_quant_kernel (q and k -> e4m3 bytes + scales in the caller's workspace), fwd_fp8_kernel.
 // The e4m3 K tile is 64 keys x 128 BYTES: byte-for-byte the geometry of a 16-bit d=64 tile, so it reuses that LDS
-// image and LDS-DMA path (TileSwz<64>, dma_stage_tile<64,...>).  Each lane reads 16 bytes of a K row per step and feeds
-// two MFMAs (low / high 8 bytes); the Q fragment in registers uses the same byte order, so the k index matches.
+// image and LDS-DMA path (TileSwz<64>, dma_stage_tile<64,...>).  Each lane reads two 16-byte chunks of a K row per
+// MFMA; the Q fragment in registers uses the same byte order, so the k index matches.
 #include "fa_common.h"
 #include "fa_kernels.h"
 
@@ -187,13 +187,19 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+            // v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit block scales (E8M0 127): 64 of the 128
+            // head-dim bytes per instruction at twice the bf16 rate per clock.  Lane (r, h) supplies 32 bytes of row r
+            // as k = 32 h .. 32 h + 31 (layout probed with tools/ubench/probe_f8f6f4.hip); which 32 bytes is free as
+            // long as K and Q agree: here the two 16-byte chunks 4M + h and 4M + 2 + h of the row.
+            typedef int i32x8_t __attribute__((ext_vector_type(8)));
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const u32x4 a = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 2 * m + h));
-                const long a_lo = ((long)a[1] << 32) | a[0], a_hi = ((long)a[3] << 32) | a[2];
-                const long b_lo = ((long)qf[m][1] << 32) | qf[m][0], b_hi = ((long)qf[m][3] << 32) | qf[m][2];
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_lo, b_lo, sacc[kb], 0, 0, 0);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_hi, b_hi, sacc[kb], 0, 0, 0);
+            for (int M = 0; M < NM / 2; ++M) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 4 * M + h));
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 4 * M + 2 + h));
+                const i32x8_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                const u32x4 b0 = qf[2 * M], b1 = qf[2 * M + 1];
+                const i32x8_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+                sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, sacc[kb], 0, 0, 0, 127, 0, 127);
             }
         }
         const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
@@ -211,9 +217,20 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
         }
         mx = fmaxf(mx, wave_half_swap(mx));
         const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
+        // lazy rescale as in fa_fwd_mfma.hip: O and l move to the new max only when some row of the wave grew by > 2^8
+        float m_use;
+        if (__any(m_new - m_run > 8.0f) != 0) {   // m_run = -inf on the first tile -> true
+            m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+        } else {
+            m_use = m_run;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -223,11 +240,7 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
                 sacc[kb][i] = p;
                 rs += p;
             }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int t2 = 0; t2 < NDV; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+        l_run += rs;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
