@@ -211,7 +211,7 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
     dim3 grid((unsigned)(((nqt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,

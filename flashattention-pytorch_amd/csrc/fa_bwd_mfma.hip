@@ -389,7 +389,7 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     {
         ProfScope ps(K_BWD_MFMA, st);
         auto launch = [&](auto kern) -> hipError_t {
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
             if (e2 != hipSuccess) return e2;
             hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                                (const uint16_t*)a.v, (const uint16_t*)a.dout, (const float*)nlse, (const float*)ndelta,

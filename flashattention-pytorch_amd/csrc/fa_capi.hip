@@ -3,6 +3,8 @@
 // enqueued on the caller's stream.
 #include "../../include/fa_mi355x.h"
 #include "fa_kernels.h"
+#include <mutex>
+#include <unordered_map>
 
 #include <atomic>
 #include <mutex>
@@ -159,6 +161,20 @@ void prof_end(int id, hipStream_t st) {
     g_prof_recs.push_back(ProfRec{id, g_prof_open[id], e});
 }
 }  // namespace fa
+
+namespace fa {
+hipError_t ensure_dynamic_smem(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(kernel);
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) granted[kernel] = bytes;
+    return e;
+}
+}  // namespace fa
+
 
 extern "C" {
 

@@ -320,7 +320,7 @@ static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_FP8, st);
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)q8, (const uint8_t*)k8, (const float*)sq,
                            (const float*)sk, (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, c);

@@ -647,7 +647,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     int dbg_flags = 0;   // staggered kernel only: its last argument carries debug ablation flags instead of the row length
     ProfScope ps(K_FWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, dbg_flags ? dbg_flags : (int)a.d);
@@ -710,7 +710,7 @@ static hipError_t launch_fwd_w4(const FwdArgs& a, hipStream_t st) {
     const float c = a.scale * 1.4426950408889634f;
     ProfScope ps(K_FWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)(nqt * a.bh)), dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, (int)a.d);

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------
 template <typename K>
 static hipError_t set_smem(K kern, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)bytes);
 }
 
 template <typename T, int DP, int NW>

@@ -41,6 +41,10 @@ struct ProfScope {
     ~ProfScope() { prof_end(id, st); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size instead of before every launch (a host
+// call of a few microseconds: visible on the small launches).  Device-wide attribute; thread safe.
+hipError_t ensure_dynamic_smem(const void* kernel, int bytes);
+
 // Tuning knobs (tile sweep / A-B runs).  Each starts from an environment variable of the same upper-case name with
 // an FA_ prefix (FA_FWD_KB, FA_FWD_STAG, FA_DKDV (4|8), FA_DQ_KT, FA_FWD_RS, FA_DKDV_KREG, FA_FWD_EAGER, FA_FWD_HS, FA_FWD_TPW, FA_DQ_TPW, FA_DKDV_TPW, FA_DQ_NLF, FA_DQ_W4, FA_FWD_ABL, FA_SMALL_GRID, FA_FP8_ROT) and can be changed at run time through
 // fa_set_option() so that variants can be interleaved in one process.
