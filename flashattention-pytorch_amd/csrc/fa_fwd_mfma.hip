@@ -341,15 +341,18 @@ bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2
 __device__ long long* g_trace = nullptr;
 hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
 
-// Staggered variant (FA_FWD_STAG=1; NOT the default: measured 2.58 ms vs 2.1-2.2 ms for the lock-step kernel at
-// B8 H32 N4096 d128, profiles/r01_tile_sweep.md).  The two waves that share a SIMD run the same program; with one barrier per tile they stay in
-// lock step, so their MFMA phases collide and their softmax (VALU) phases collide, and the tile time is the SUM of
-// the two.  Here every tile is split in two halves separated by barriers,
+// Staggered ("ping-pong") forward, option fwd_stag = 1 (d = 128): 2.01-2.10 ms against 2.09-2.23 for the lock-step kernel
+// above at B8 H32 N4096 on most boxes, equal on the slowest (profiles/r01_tile_sweep.md); not the default (see launch_fwd_kb).  The two waves that share a SIMD run the same program; with
+// one barrier per tile they stay in lock step, so their MFMA phases collide and their softmax (VALU) phases collide, and
+// the tile time is close to the SUM of the two.  Here every 64-key tile is split in two halves separated by barriers,
 //     M_t = [ O^T += V^T P^T (tile t-1) ; S^T = K Q^T (tile t) ]      matrix pipe
 //     V_t = [ online softmax of tile t, O rescale, pack P ]           vector pipe
 // and waves 4..7 run half a tile behind waves 0..3, so at any time one wave of a SIMD is in M and the other in V.
-// LDS-DMA is issued at even global half-steps g = 2u: K(u+1) and V(u); K and V are each double buffered (V lags K by
-// one tile), which keeps every buffer alive exactly as long as the later half of the workgroup reads it.
+// A wave that is alone on the matrix pipe gets no latency cover from its partner, so the M phase is hand timed: LDS
+// operand reads from inline asm three MFMAs ahead (a 4-slot ring, the first slots filled before the barrier), counted
+// lgkmcnt waits fused to each MFMA, P.V and S accumulation chains interleaved.  K and V are triple buffered with the
+// LDS-DMA issued two tiles ahead at even global half-steps g = 2u (K(u+2), V(u+1)) and counted vmcnt waits, so a
+// transfer has four half-steps to land.
 template <typename Tag, int D, bool CAUSAL, int KB>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
@@ -637,28 +640,27 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
 static int fwd_kb_override() { return option(OPT_FWD_KB); }
 
 template <typename Tag, int D, int KB, bool PAD = false>
-static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st) {
+static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag = false) {
     constexpr int NW = D == 256 ? 4 : 8, BM = 32 * NW;
     const int nqt = (int)((a.n + BM - 1) / BM);
     size_t smem = 2 * 2 * (32 * KB) * D * 2;
     if (smem < (size_t)NW * 32 * D * 2) smem = (size_t)NW * 32 * D * 2;   // the epilogue stages the BM x D output tile in LDS
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
-    int dbg_flags = 0;   // staggered kernel only: its last argument carries debug ablation flags instead of the row length
+    int last_arg = (int)a.d;   // row length; the staggered kernel takes debug ablation flags in this slot instead
     ProfScope ps(K_FWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, dbg_flags ? dbg_flags : (int)a.d);
+                           (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, last_arg);
         return hipGetLastError();
     };
-    // experimental schedules (sweep evidence only): built for bf16, d = 128, 64-key tiles; anything else runs lock-step
-    if constexpr (std::is_same<Tag, bf16_tag>::value && D == 128 && KB == 2 && !PAD) {
-        const int stag = option(OPT_FWD_STAG);
-        if (stag) {
+    // staggered schedule (fwd_mfma_stag_kernel): d = 128, 64-key tiles
+    if constexpr (D == 128 && KB == 2 && !PAD) {
+        if (want_stag) {
             smem = (size_t)6 * (32 * KB) * D * 2;   // K and V, three buffers each
-            dbg_flags = option(OPT_FWD_ABL);
+            last_arg = option(OPT_FWD_STAG) == 1 ? option(OPT_FWD_ABL) : 0;
             return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
         }
     }
@@ -731,9 +733,14 @@ bool small_grid(int64_t bh, int64_t n) {
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
-    const bool experimental = option(OPT_FWD_STAG) != 0;
+    // Schedule: lock step by default.  The staggered kernel (option fwd_stag = 1; one wave of a SIMD in its matrix phase
+    // while the other is in its vector phase) measures -1 ... -5.5 % for non-causal d = 128 depending on the box
+    // (profiles/r01_tile_sweep.md) and loses under the causal mask; it also uses 64-key tiles, so making it the default
+    // for large launches only would break the bitwise equality of a (b,h) unit's result across launch sizes.
+    const bool stag = D == 128 && option(OPT_FWD_STAG) == 1;
+    if (stag) return launch_fwd_t<Tag, D, 2>(a, st, true);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
-    if (kb == 2 || experimental) return launch_fwd_t<Tag, D, 2>(a, st);   // the experimental schedules use 64-key tiles
+    if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
     return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key (LDS 128 KiB at d = 128)
 }
 
@@ -746,7 +753,7 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
     }
-    const bool sweeping = option(OPT_FWD_KB) || option(OPT_FWD_STAG) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
+    const bool sweeping = option(OPT_FWD_KB) || option(OPT_FWD_STAG) == 1 || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
                           option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
     if (!sweeping && small_grid(a.bh, a.n)) {
         if (a.dtype == 2) return a.d == 128 ? launch_fwd_w4<bf16_tag, 128>(a, st) : launch_fwd_w4<bf16_tag, 64>(a, st);

@@ -13,7 +13,7 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [
     ("base", {}),
-    ("fwd: staggered halves + pinned operand prefetch (64-key tiles)", {"fwd_stag": 1}),
+    ("fwd: staggered kernel (64-key tiles)", {"fwd_stag": 1}),
     ("fwd: lock-step 64-key tiles", {"fwd_kb": 2}),
 ]
 ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl"]
