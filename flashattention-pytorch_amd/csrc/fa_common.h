@@ -227,7 +227,9 @@ __device__ __forceinline__ int dma_lane_voff(int lane, int w, int dr = D) {
 // ds_read_b64_tr_b16 as possibly aliasing the pending LDS write and parks the wave on s_waitcnt vmcnt(0) in the
 // middle of the tile (the DMA's whole latency exposed).  The price: nothing waits for the data unless we do —
 // dma_wait_all() (s_waitcnt vmcnt(0)) must precede the barrier after which other waves read the tile.
-// M0 carries the LDS base for the instruction; it is saved/restored around it (hipcc reserves M0).
+// M0 carries the LDS base for the instruction.  hipcc reserves M0 and keeps nothing in it across statements, so it is
+// written here and not restored.  The s_mov + s_nop 3 are the five wait states a buffer instruction needs after a
+// v_readfirstlane wrote one of its SGPR operands (the soffset), which also covers the one state M0 needs.
 typedef u32x4 rsrc_s_t;   // buffer descriptor held in SGPRs (every word wave-uniform)
 __device__ __forceinline__ rsrc_s_t make_rsrc_s(const void* base, unsigned bytes) {
     const uint64_t a = (uint64_t)base;
@@ -246,14 +248,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
 }
 __device__ __forceinline__ void dma16_issue(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                 :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void dma4_issue(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dword %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 3\n\tbuffer_load_dword %0, %2, %3 offen lds"
+                 :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -26,7 +26,8 @@ namespace fa {
 
 // ABL != 0: ablation builds for profiling only (wrong results on purpose; option fwd_abl, tools/ab.py):
 //   bit 0: no exp2 / max / sum (P = S packed as is)   bit 1: no LDS-DMA, no barrier (every tile re-reads buffer 0)
-//   bit 2: no LDS operand reads (K and V^T fragments are register constants)
+//   bit 2: no LDS operand reads (K and V^T fragments are register constants)   bit 3: no LDS-DMA, barrier kept
+//   bit 4: LDS-DMA issued but never waited for
 // W4 (d <= 128): 4 waves = 128 query rows per workgroup, for launches whose 256-row tiles would leave CUs idle
 // (bh * ceil(N / 256) below the CU count): twice the workgroups, each with one wave per SIMD.
 template <typename Tag, int D, bool CAUSAL, int KB, bool RS_MFMA, bool LAZY, bool HS, int TPW, bool PAD, int ABL = 0, bool W4 = false>
@@ -127,8 +128,8 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
     const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
     for (int t = 0; t < ntiles_w; ++t) {
         const int k0 = t * BN;
-        const int cur = (ABL & 2) ? 0 : (gbase + t) & 1;
-        if (!(ABL & 2)) stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
+        const int cur = (ABL & 10) ? 0 : (gbase + t) & 1;
+        if (!(ABL & 10)) stage_next(t);   // nobody reads that buffer: all waves passed the last barrier
 
         const char* Kt = smem + cur * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
             l_run += rs;
         }
         if (!(ABL & 2)) {
-        dma_wait_all();   // this wave's share of the next tile has landed ...
+        if (!(ABL & 16)) dma_wait_all();   // this wave's share of the next tile has landed ...
         __syncthreads();  // ... and so has everyone else's
         }
     }
@@ -680,6 +681,8 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
             case 4: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 4>);
             case 6: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 6>);
             case 7: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 7>);
+            case 8: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 8>);
+            case 16: return launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, PAD, 16>);
             default: break;
         }
     }
