@@ -11,10 +11,10 @@ sys.path.insert(0, "flashattention-pytorch_amd")
 import torch
 import flashattention_lab_cuda as ext
 
-VARIANTS = [
+VARIANTS = [   # edit to taste: every key of ALL_KEYS is an fa_set_option name (csrc/fa_kernels.h)
     ("base", {}),
-    ("fwd ablation 8: no LDS-DMA (every tile re-reads buffer 0), barrier kept", {"fwd_abl": 8}),
-    ("fwd ablation 16: LDS-DMA issued, never waited for", {"fwd_abl": 16}),
+    ("fwd: staggered kernel (64-key tiles)", {"fwd_stag": 1}),
+    ("fwd: lock-step 64-key tiles", {"fwd_kb": 2}),
 ]
 ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl"]
 
