@@ -20,9 +20,10 @@ template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF,
 __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
-                                                             const float* __restrict__ nlse,
-                                                             const float* __restrict__ ndelta, uint16_t* __restrict__ dq,
-                                                             int n, int nqt, float c_log2, float scale, int dr) {
+                                                             const uint16_t* __restrict__ o, const float* __restrict__ lse,
+                                                             float* __restrict__ nlse, float* __restrict__ ndelta,
+                                                             uint16_t* __restrict__ dq, int n, int nqt, float c_log2,
+                                                             float scale, int dr) {
     const int DR = PAD ? dr : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     // D = 256: 4 waves, one per SIMD, with the whole 512-register file each (Q, dO fragments 128 + dQ^T 128 registers)
     // W4 (d <= 128): the same 4-wave shape but TWO workgroups per CU — the two waves of a SIMD then belong to different
@@ -48,17 +49,33 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
 
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
     const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * DR * 2);
+    const buf_rsrc_t y_rs = make_rsrc(o + base, (unsigned)n * DR * 2);   // the forward's output
     s16x8 qf[NKS], of[NKS];
     float nl, nd;   // row constants of this lane's query; a padded row gets S' = -1e30 -> P = 0
+    // The row constants are made here, where a query row's dO is in registers anyway: -delta = -rowsum(dO * O)
+    // (csrc/fa2/fa2_bwd.cu:57) from this lane's half of the row plus the other half's in lane ^ 32, and -lse / scale.
+    // They are also stored for the dK/dV kernel, which is launched after this one (no separate preparation launch).
     auto load_rows = [&](int qt_) {
         const int row = qt_ * BM + 32 * w + r;
+        float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             qf[ks] = buf_load_frag(q_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
             of[ks] = buf_load_frag(o_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
+            const s16x8 yf = buf_load_frag(y_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
+            const u32x4 a = *reinterpret_cast<const u32x4*>(&of[ks]), b = *reinterpret_cast<const u32x4*>(&yf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                part += unpack_lo<Tag>(a[j]) * unpack_lo<Tag>(b[j]) + unpack_hi<Tag>(a[j]) * unpack_hi<Tag>(b[j]);
         }
-        nl = row < n ? nlse[(size_t)bh * n + row] : -1e30f;
-        nd = row < n ? ndelta[(size_t)bh * n + row] : 0.f;
+        part += wave_half_swap(part);
+        const bool live = row < n;
+        nl = live ? -lse[(size_t)bh * n + row] / scale : -1e30f;
+        nd = live ? -part : 0.f;
+        if (live && h == 0) {
+            nlse[(size_t)bh * n + row] = nl;
+            ndelta[(size_t)bh * n + row] = nd;
+        }
     };
     load_rows(tile_of(0));
 
@@ -198,7 +215,7 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
 }
 
 template <typename Tag, int D, int KT, bool PAD = false, bool W4 = false>
-static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+static hipError_t launch_dq_kt(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
     constexpr int NW = (D == 256 || W4) ? 4 : 8, BM = 32 * NW;
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = 2 * 2 * (64 * KT) * D * 2;
@@ -214,7 +231,7 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
-                           (const uint16_t*)a.v, (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
+                           (const uint16_t*)a.v, (const uint16_t*)a.dout, (const uint16_t*)a.o, a.lse, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
                            a.scale, (int)a.d);
         return hipGetLastError();
     };
@@ -240,13 +257,13 @@ static hipError_t launch_dq_kt(const BwdArgs& a, const float* nlse, const float*
 // K/V tile of the dQ pass: 64 keys per barrier is the measured winner (2.98 vs 3.43 ms, profiles/r01_tile_sweep.md);
 // option dq_kt=2 selects two 64-key sub-tiles per barrier (sweep)
 template <typename Tag, int D>
-static hipError_t launch_dq_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+static hipError_t launch_dq_t(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
     if (option(OPT_DQ_W4) == 1 || (option(OPT_DQ_W4) == 0 && option(OPT_DQ_KT) == 0 && option(OPT_DQ_TPW) == 0 && small_grid(a.bh, a.n)))
         return launch_dq_kt<Tag, D, 1, false, true>(a, nlse, ndelta, st);
     return option(OPT_DQ_KT) == 2 ? launch_dq_kt<Tag, D, 2>(a, nlse, ndelta, st) : launch_dq_kt<Tag, D, 1>(a, nlse, ndelta, st);
 }
 
-hipError_t launch_bwd_dq_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dq_kt<bf16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 256, 1, true>(a, nlse, ndelta, st);
         return a.d == 256 ? launch_dq_kt<f16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 256, 1, true>(a, nlse, ndelta, st);

@@ -4,7 +4,8 @@
 //   delta = rowsum(dO * O);  per (K tile, Q tile): P = exp(S - lse), dV += P^T dO, dP = dO V^T,
 //   dS = P * (dP - delta), dQ += dS K * scale, dK += dS^T Q * scale        (fp32 accumulation).
 //
-// Three launches:
+// This file: the single-kernel backward kept for the sweep (the default split backward is fa_bwd_dq_mfma.hip +
+// fa_bwd_dkdv_mfma.hip, dispatched from launch_bwd_t below).  Three launches:
 //   1. bwd_prep_kernel   : nlse = -lse / scale, ndelta = -rowsum(dO*O)   (row constants, fp32 workspace)
 //   2. bwd_mfma_kernel   : one workgroup = 4 waves = 256 keys of one (b,h); every wave keeps dK^T and dV^T of
 //                          its 64 keys in 256 accumulator registers (one wave per SIMD, 512-register budget)
@@ -366,21 +367,22 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
         e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
         if (e != hipSuccess) return e;
     }
-    {
+    // Split backward (default): the dQ kernel runs first and makes the row constants nlse = -lse / scale and
+    // ndelta = -rowsum(dO * O) on its way (it holds every query row's dO in registers), the dK/dV kernel reads them.
+    // FA_DKDV=4 selects the 4-wave / 512-register dK/dV kernel below instead (tile sweep evidence).
+    const int dkdv_env = option(OPT_DKDV);
+    if (pad || (!fused && dkdv_env != 4)) {
+        e = launch_bwd_dq_mfma(a, nlse, ndelta, st);
+        if (e != hipSuccess) return e;
+        return launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
+    }
+    {   // the single-kernel / 4-wave variants take their row constants from a preparation launch
         ProfScope ps(K_BWD_DELTA, st);
         hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
                            (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, (int)a.d, 1.0f / a.scale);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // dK/dV pass of the split backward: the 8-wave kernel (two waves per SIMD) where its register budget holds
-    // is the default; FA_DKDV=w4 selects the 4-wave / 512-register kernel below (tile sweep evidence).
-    const int dkdv_env = option(OPT_DKDV);
-    if (pad || (!fused && dkdv_env != 4)) {
-        e = launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
-        if (e != hipSuccess) return e;
-        return launch_bwd_dq_mfma(a, nlse, ndelta, st);
-    }
     if constexpr (D != 256) {
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * 32 * D * 2 + BK * 32 * 2 + 2 * 64 * sizeof(float);
