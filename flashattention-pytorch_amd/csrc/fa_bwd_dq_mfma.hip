@@ -16,7 +16,10 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF, bool W4>
+// PREP: make the row constants here (and store them for the dK/dV kernel) instead of reading them.  On for the 128-
+// and 256-wide tiles; at d <= 64 a workgroup's main loop is too short to hide the extra prologue read of O and the
+// separate bwd_prep_kernel launch is cheaper (1.50 vs 1.62 ms at N=4096, profiles/r01_tile_sweep.md).
+template <typename Tag, int D, bool CAUSAL, int KT, int TPW, bool PAD, bool NLF, bool W4, bool PREP = (D > 64)>
 __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -57,24 +60,31 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
     // They are also stored for the dK/dV kernel, which is launched after this one (no separate preparation launch).
     auto load_rows = [&](int qt_) {
         const int row = qt_ * BM + 32 * w + r;
+        const bool live = row < n;
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             qf[ks] = buf_load_frag(q_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
             of[ks] = buf_load_frag(o_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
-            const s16x8 yf = buf_load_frag(y_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
-            const u32x4 a = *reinterpret_cast<const u32x4*>(&of[ks]), b = *reinterpret_cast<const u32x4*>(&yf);
+            if (PREP) {
+                const s16x8 yf = buf_load_frag(y_rs, frag_off(row, 16 * ks + 8 * h, DR, PAD));
+                const u32x4 a = *reinterpret_cast<const u32x4*>(&of[ks]), b = *reinterpret_cast<const u32x4*>(&yf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                part += unpack_lo<Tag>(a[j]) * unpack_lo<Tag>(b[j]) + unpack_hi<Tag>(a[j]) * unpack_hi<Tag>(b[j]);
+                for (int j = 0; j < 4; ++j)
+                    part += unpack_lo<Tag>(a[j]) * unpack_lo<Tag>(b[j]) + unpack_hi<Tag>(a[j]) * unpack_hi<Tag>(b[j]);
+            }
         }
-        part += wave_half_swap(part);
-        const bool live = row < n;
-        nl = live ? -lse[(size_t)bh * n + row] / scale : -1e30f;
-        nd = live ? -part : 0.f;
-        if (live && h == 0) {
-            nlse[(size_t)bh * n + row] = nl;
-            ndelta[(size_t)bh * n + row] = nd;
+        if (PREP) {
+            part += wave_half_swap(part);
+            nl = live ? -lse[(size_t)bh * n + row] / scale : -1e30f;
+            nd = live ? -part : 0.f;
+            if (live && h == 0) {
+                nlse[(size_t)bh * n + row] = nl;
+                ndelta[(size_t)bh * n + row] = nd;
+            }
+        } else {
+            nl = live ? nlse[(size_t)bh * n + row] : -1e30f;
+            nd = live ? ndelta[(size_t)bh * n + row] : 0.f;
         }
     };
     load_rows(tile_of(0));
@@ -220,10 +230,10 @@ static hipError_t launch_dq_kt(const BwdArgs& a, float* nlse, float* ndelta, hip
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = 2 * 2 * (64 * KT) * D * 2;
     const float c = a.scale * 1.4426950408889634f;
-    // query tiles per workgroup: 2 under the causal mask (heavy + light pair: -9 ... -11 %), 1 otherwise (±1-2 %);
+    // query tiles per workgroup: 2 under the causal mask (heavy + light pair: -9 ... -11 %) and at d = 128 (-1.7 %), else 1;
     // option dq_tpw overrides (1 | 2)
     int tpw = option(OPT_DQ_TPW);
-    if (tpw == 0) tpw = (KT == 1 && a.causal) ? 2 : 1;
+    if (tpw == 0) tpw = (KT == 1 && (a.causal || D == 128)) ? 2 : 1;   // the fused prologue (PREP) is worth hiding at d = 128
     if (KT != 1 || D == 256) tpw = 1;
     dim3 grid((unsigned)(((nqt + tpw - 1) / tpw) * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);

@@ -367,11 +367,12 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
         e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);
         if (e != hipSuccess) return e;
     }
-    // Split backward (default): the dQ kernel runs first and makes the row constants nlse = -lse / scale and
+    // Split backward (default).  d > 64: the dQ kernel runs first and makes the row constants nlse = -lse / scale and
     // ndelta = -rowsum(dO * O) on its way (it holds every query row's dO in registers), the dK/dV kernel reads them.
-    // FA_DKDV=4 selects the 4-wave / 512-register dK/dV kernel below instead (tile sweep evidence).
+    // d <= 64: a preparation launch makes them (fa_bwd_dq_mfma.hip, PREP).  FA_DKDV=4 selects the 4-wave dK/dV kernel.
     const int dkdv_env = option(OPT_DKDV);
-    if (pad || (!fused && dkdv_env != 4)) {
+    const bool split = pad || (!fused && dkdv_env != 4);
+    if (split && dq_makes_row_constants(a.d)) {
         e = launch_bwd_dq_mfma(a, nlse, ndelta, st);
         if (e != hipSuccess) return e;
         return launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
@@ -383,6 +384,11 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (split) {
+        e = launch_bwd_dkdv_mfma(a, nlse, ndelta, st);
+        if (e != hipSuccess) return e;
+        return launch_bwd_dq_mfma(a, nlse, ndelta, st);
+    }
     if constexpr (D != 256) {
     const int nkt = (int)((a.n + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * 32 * D * 2 + BK * 32 * 2 + 2 * 64 * sizeof(float);
