@@ -15,7 +15,7 @@
 
 namespace fa {
 
-template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD, bool W4 = false>
+template <typename Tag, int D, bool CAUSAL, bool KREG, int TPW, bool PAD, bool W4 = false, bool STG = false>
 __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) void bwd_dkdv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v,
                                                                const uint16_t* __restrict__ dout,
@@ -215,7 +215,29 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
     // the K tile and both Q/dO buffers are free: the next key tile's loads go out ahead of the stores.
     const int kt_next = (TPW > 1 && ip + 1 < TPW) ? tile_of(ip + 1) : -1;
     if (TPW > 1 && kt_next >= 0) begin_tile(kt_next);
-    if (key < n) {
+    if (STG && TPW == 1 && D != 256) {
+        // (one key tile per workgroup; the paired form keeps the direct stores: a second epilogue path costs it spills)
+        // the K tile in LDS is dead, so each wave stages its 32 x D results in its own
+        // 32-row slice of it and stores whole rows (1 KiB per instruction instead of 64 scattered 8-byte pieces)
+        char* stg = Ks + w * 32 * D * 2;
+        u32x2 vals[NDB * 4];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vals[4 * db + g][0] = pack2_rn<Tag>(dka[db][4 * g + 0] * scale, dka[db][4 * g + 1] * scale);
+                vals[4 * db + g][1] = pack2_rn<Tag>(dka[db][4 * g + 2] * scale, dka[db][4 * g + 3] * scale);
+            }
+        store_rows_via_lds<D>(stg, vals, dk + base, kw0, n, lane, DR);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vals[4 * db + g][0] = pack2_rn<Tag>(dva[db][4 * g + 0], dva[db][4 * g + 1]);
+                vals[4 * db + g][1] = pack2_rn<Tag>(dva[db][4 * g + 2], dva[db][4 * g + 3]);
+            }
+        store_rows_via_lds<D>(stg, vals, dv + base, kw0, n, lane, DR);
+    } else if (key < n) {
         uint16_t* dkrow = dk + base + (size_t)key * DR;
         uint16_t* dvrow = dv + base + (size_t)key * DR;
 #pragma unroll
@@ -264,6 +286,12 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
     }
     if (tpw == 2)
         return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2, PAD, W4>);
+    // staged row stores in the epilogue (option dkdv_stg: 1 on, 2 off; default by measurement, see the sweep notes)
+    const int so = option(OPT_DKDV_STG);
+    const bool stg = so == 1 || (so == 0 && D == 128);
+    if constexpr (!PAD && !W4) {
+        if (stg) return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1, PAD, W4, true>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1, PAD, W4, true>);
+    }
     return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 1, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 1, PAD, W4>);
 }
 
