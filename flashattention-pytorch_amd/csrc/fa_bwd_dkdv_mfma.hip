@@ -1,4 +1,5 @@
-// FlashAttention backward, dK/dV pass, for gfx950 (bf16 / f16, head_dim 64 or 128) — two waves per SIMD.
+// FlashAttention backward, dK/dV pass, for gfx950 (bf16 / f16; 64- and 128-wide tiles with two waves per SIMD, 256-wide
+// tiles and small launches with 4-wave workgroups; narrower head dims padded).
 //
 //   dV[key] = sum_q P[q][key] dO[q],   dK[key] = scale * sum_q dS[q][key] Q[q]
 //   P = exp(S - lse), dS = P * (dO V^T - delta)            (csrc/fa2/fa2_bwd.cu:91-104, the dK/dV half)

@@ -1,4 +1,5 @@
-// FlashAttention backward, dQ pass, for gfx950 (bf16 / f16, head_dim 64 or 128).
+// FlashAttention backward, dQ pass, for gfx950 (bf16 / f16; 64-, 128- and 256-wide tiles, narrower head dims padded).
+// Launched FIRST at d > 64: it also makes the row constants -lse/scale and -rowsum(dO*O) for the dK/dV pass (PREP).
 //
 //   dQ[q] = scale * sum_key dS[q][key] K[key],   dS = P * (dP - delta),  P = exp(S - lse),  dP = dO V^T
 //   (csrc/fa2/fa2_bwd.cu:91-103 restricted to the dQ accumulation; S and dP are recomputed here so that the

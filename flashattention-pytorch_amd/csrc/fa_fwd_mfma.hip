@@ -4,9 +4,10 @@
 // S = QK^T -> scale -> mask -> online softmax -> O += PV, fp32 accumulation, `o` in the input dtype, `lse` fp32.
 //
 // Decomposition (wave64, MFMA 32x32x16):
-//   workgroup = 8 waves = 256 query rows of one (b,h); each wave owns 32 query rows.
-//   K/V tiles of 64 keys are staged global -> registers -> LDS (XOR-swizzled rows, double buffered,
-//   one barrier per tile); Q stays in registers as the B operand.
+//   workgroup = 8 waves = 256 query rows of one (b,h); each wave owns 32 query rows (4 waves = 128 rows for the
+//   256-wide tiles and for small launches).  K/V tiles of 128 keys go HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds; the
+//   XOR swizzle is applied to the source address), double buffered, one barrier per tile; Q stays in registers as the
+//   B operand.  A workgroup may work through two query tiles (persistent; causal heavy + light pairing).
 //   S^T = K . Q^T  ("swapped" product): the 32x32 accumulator then has the QUERY on the lane
 //   (col = lane & 31) and 16 keys per lane in registers, so the running max / sum of a query row are
 //   per-lane scalars: the row reductions are in-register plus one exchange with lane ^ 32.
