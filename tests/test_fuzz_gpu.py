@@ -1,0 +1,51 @@
+"""GPU: seeded random shapes through the C ABI against the fp64 oracle — head dims 8..256 (padded tiles, 256-wide tiles),
+ragged N, odd numbers of tiles (the causal heavy+light pairing), small and large launches (4-wave and 8-wave tilings)."""
+import os
+import random
+
+import pytest
+import torch
+
+from oracle import attention_oracle as orc
+from tests.helpers import dtype_tolerances, make_qkv
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(count, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(count):
+        d = rng.choice([8, 16, 24, 40, 48, 64, 64, 72, 96, 104, 128, 128, 128, 136, 192, 256])
+        if i % 5 == 4:   # a launch large enough for the 8-wave kernels: bh * ceil(n / 256) >= 224
+            n = rng.choice([257, 300, 511, 512, 700])
+            bh = 224 // ((n + 255) // 256) + rng.randint(1, 6)
+            d = rng.choice([40, 64, 96, 128, 256])
+        else:
+            n = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 513, 767, 769, 1023, 1025, 1300])
+            bh = rng.randint(1, 5)
+        out.append((bh, n, d, rng.random() < 0.5, rng.choice([torch.bfloat16, torch.float16]), 1000 + i))
+    return out
+
+
+# FA_FUZZ_CASES / FA_FUZZ_SEED widen the sweep for a one-off soak (default: 40 cases, fixed seed)
+@pytest.mark.parametrize("bh,n,d,causal,dtype,seed",
+                         _cases(int(os.environ.get("FA_FUZZ_CASES", "40")), int(os.environ.get("FA_FUZZ_SEED", "20261004"))),
+                         ids=lambda v: str(v).replace("torch.", "") if not isinstance(v, bool) else ("causal" if v else "full"))
+def test_random_shape_matches_oracle(bh, n, d, causal, dtype, seed, device):
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = make_qkv(bh, n, d, dtype, seed=seed)
+    scale = d ** -0.5
+    # the oracle is O(bh * n^2 * d) in fp64 on the CPU: check a few (b,h) units of the large launches
+    sel = list(range(bh)) if bh <= 6 else [0, bh // 2, bh - 1]
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q[sel], k[sel], v[sel], do[sel], causal, scale, math_dtype=torch.float64)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    o, lse = ext.forward(qd, kd, vd, causal, scale, 64, 128)
+    dq, dk, dv = ext.backward(qd, kd, vd, o, dod, lse, causal, scale, 64, 128)
+    tol = dtype_tolerances(dtype)
+    for name, got, want in (("o", o, ro), ("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        g = got[sel].cpu()
+        assert torch.isfinite(g.float()).all(), name
+        torch.testing.assert_close(g, want, **tol, msg=lambda m: f"{name}: {m}")
+    torch.testing.assert_close(lse[sel].cpu(), rlse, rtol=1e-3, atol=1e-3)
