@@ -13,7 +13,7 @@ import flashattention_lab_cuda as ext
 
 VARIANTS = [   # edit to taste: every key of ALL_KEYS is an fa_set_option name (csrc/fa_kernels.h)
     ("base", {}),
-    ("dkdv: staged row stores", {"dkdv_stg": 1}),
+    ("fwd: staggered kernel (64-key tiles)", {"fwd_stag": 1}),
     ("dkdv: direct 8-byte stores", {"dkdv_stg": 2}),
 ]
 ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg"]
