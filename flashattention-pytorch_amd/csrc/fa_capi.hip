@@ -165,12 +165,16 @@ void prof_end(int id, hipStream_t st) {
 namespace fa {
 hipError_t ensure_dynamic_smem(const void* kernel, int bytes) {
     static std::mutex mu;
-    static std::unordered_map<const void*, int> granted;
+    static std::unordered_map<uint64_t, int> granted;   // (device, kernel) -> bytes: the attribute is per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t key = reinterpret_cast<uint64_t>(kernel) ^ (static_cast<uint64_t>(dev + 1) << 56);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = granted.find(kernel);
+    auto it = granted.find(key);
     if (it != granted.end() && it->second >= bytes) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) granted[kernel] = bytes;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) granted[key] = bytes;
     return e;
 }
 }  // namespace fa
