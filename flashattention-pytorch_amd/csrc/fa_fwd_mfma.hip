@@ -343,8 +343,8 @@ bool fwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2
 __device__ long long* g_trace = nullptr;
 hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
 
-// Staggered ("ping-pong") forward, option fwd_stag = 1 (d = 128): 2.01-2.10 ms against 2.09-2.23 for the lock-step kernel
-// above at B8 H32 N4096 on most boxes, equal on the slowest (profiles/r01_tile_sweep.md); not the default (see launch_fwd_kb).  The two waves that share a SIMD run the same program; with
+// Staggered ("ping-pong") forward: the DEFAULT at d = 128 with 128-key tiles (1.95 ms against 2.14 for the lock-step kernel
+// above at B8 H32 N4096, bitwise the same results; profiles/r01_tile_sweep.md); also built with 64-key tiles (fwd_stag = 1).  The two waves that share a SIMD run the same program; with
 // one barrier per tile they stay in lock step, so their MFMA phases collide and their softmax (VALU) phases collide, and
 // the tile time is close to the SUM of the two.  Here every 64-key tile is split in two halves separated by barriers,
 //     M_t = [ O^T += V^T P^T (tile t-1) ; S^T = K Q^T (tile t) ]      matrix pipe
@@ -362,9 +362,12 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
                                                                float scale, int dbg /* debug ablation flags (option fwd_abl), 0 in production */) {
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | K1 | K2 | V0 | V1 | V2]: tile t in buffer t % 3
+    // 64-key tiles: K and V triple buffered, DMA two tiles ahead.  128-key tiles (160 KB of LDS do not hold six of them):
+    // double buffered, DMA one tile ahead, which is as much time because the phases are twice as long.
+    constexpr int NBUF = KB == 4 ? 2 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [K x NBUF | V x NBUF]: tile t in buffer t % NBUF
     char* Kbuf = smem;
-    char* Vbuf = smem + 3 * TILE_BYTES;
+    char* Vbuf = smem + NBUF * TILE_BYTES;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = L / nqt;
@@ -396,8 +399,13 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     constexpr int DMA_PER_ISSUE = 2 * (BN / (512 / D)) / 8;
     auto issue = [&](int u) {
         if (dbg & 4) return;                                   // ablation: no DMA
-        dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 2) % 3) * TILE_BYTES, (u + 2) * BN, dma_voff, w);
-        dma_stage_tile<D, BN, 8>(v_rs, Vbuf + ((u + 1) % 3) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
+        if (NBUF == 3) {
+            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 2) % 3) * TILE_BYTES, (u + 2) * BN, dma_voff, w);
+            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + ((u + 1) % 3) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
+        } else {   // K(u+1), V(u): first read in half-step 2u+2
+            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 1) & 1) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
+            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (u & 1) * TILE_BYTES, u * BN, dma_voff, w);
+        }
     };
 
     f32x16 oacc[NDV];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
         };
         // this phase's buffers folded into the lane addresses once; everything else is an immediate offset
         if constexpr (WHICH == 0) {
-            const unsigned vsel = (t % 3) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % 3) * TILE_BYTES;
+            const unsigned vsel = (t % NBUF) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % NBUF) * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) kq[ks] = ka[ks] + ksel;
 #pragma unroll
@@ -588,13 +596,15 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     };
     auto end_half = [&](int gg) {
         stamp();
-        if (gg & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_ISSUE) : "memory");
+        if (gg & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF == 3 ? DMA_PER_ISSUE : 0) : "memory");
         __syncthreads();
         stamp();
     };
     dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w);
-    dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w);
-    dma_stage_tile<D, BN, 8>(v_rs, Vbuf, 0, dma_voff, w);
+    if (NBUF == 3) {
+        dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(v_rs, Vbuf, 0, dma_voff, w);
+    }
     dma_wait_all();
     __syncthreads();
     int g = 0;
@@ -606,9 +616,12 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     for (int t = 0; t < Tw; ++t) {
         if (!(g & 1)) issue(g >> 1);
         do_softmax(t);                                        // V_t
-        do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, t);   // first operands of M_{t+1}: both tiles landed a step ago
+        // first operands of M_{t+1} ahead of the barrier — with three buffers both tiles landed a step ago; with two the
+        // tiles are only guaranteed after this barrier, so the requests follow it
+        if (NBUF == 3) do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, t);
         end_half(g); ++g;
         if (!(g & 1)) issue(g >> 1);
+        if (NBUF != 3) do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, t);
         do_M(std::true_type{}, std::true_type{}, std::integral_constant<int, 1>{}, t);          // M_{t+1} = P.V(t) ; S(t+1)  (after the last tile S is unused:
                                                               // one code path keeps the accumulators in place)
         end_half(g); ++g;
@@ -658,10 +671,10 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
                            (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, last_arg);
         return hipGetLastError();
     };
-    // staggered schedule (fwd_mfma_stag_kernel): d = 128, 64-key tiles
-    if constexpr (D == 128 && KB == 2 && !PAD) {
+    // staggered schedule (fwd_mfma_stag_kernel): d = 128, 64-key tiles (three buffers each) or 128-key tiles (two)
+    if constexpr (D == 128 && (KB == 2 || KB == 4) && !PAD) {
         if (want_stag) {
-            smem = (size_t)6 * (32 * KB) * D * 2;   // K and V, three buffers each
+            smem = (size_t)2 * (KB == 4 ? 2 : 3) * (32 * KB) * D * 2;
             last_arg = option(OPT_FWD_STAG) == 1 ? option(OPT_FWD_ABL) : 0;
             return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
         }
@@ -737,11 +750,13 @@ bool small_grid(int64_t bh, int64_t n) {
 template <typename Tag, int D>
 static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     const int kb = fwd_kb_override();
-    // Schedule: lock step by default.  The staggered kernel (option fwd_stag = 1; one wave of a SIMD in its matrix phase
-    // while the other is in its vector phase) measures -1 ... -5.5 % for non-causal d = 128 depending on the box
-    // (profiles/r01_tile_sweep.md) and loses under the causal mask; it also uses 64-key tiles, so making it the default
-    // for large launches only would break the bitwise equality of a (b,h) unit's result across launch sizes.
-    const bool stag = D == 128 && option(OPT_FWD_STAG) == 1;
+    // Schedule at d = 128: the staggered kernel with 128-key tiles is the default (-9 % non-causal, -2 ... -10 % causal
+    // against lock step, profiles/r01_tile_sweep.md; bitwise the same results, it performs the same operations in the
+    // same order).  Option fwd_stag: 1 = staggered with 64-key tiles, 2 = lock step, 3 = staggered with 128-key tiles.
+    const int so = option(OPT_FWD_STAG);
+    const bool other_sweep = kb || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) || option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
+    if (D == 128 && (so == 3 || (so == 0 && !other_sweep))) return launch_fwd_t<Tag, D, 4>(a, st, true);
+    const bool stag = D == 128 && so == 1;
     if (stag) return launch_fwd_t<Tag, D, 2>(a, st, true);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
@@ -757,7 +772,7 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
     }
-    const bool sweeping = option(OPT_FWD_KB) || option(OPT_FWD_STAG) == 1 || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
+    const bool sweeping = option(OPT_FWD_KB) || (option(OPT_FWD_STAG) & 1) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
                           option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
     if (!sweeping && small_grid(a.bh, a.n)) {
         if (a.dtype == 2) return a.d == 128 ? launch_fwd_w4<bf16_tag, 128>(a, st) : launch_fwd_w4<bf16_tag, 64>(a, st);

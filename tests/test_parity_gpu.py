@@ -291,7 +291,7 @@ def test_backward_variants_agree_and_split_is_deterministic(causal, d, device):
 
 
 FWD_OPTIONS = [
-    {"fwd_stag": 1}, {"fwd_kb": 2}, {"fwd_kb": 1}, {"fwd_tpw": 1}, {"fwd_tpw": 2}, {"fwd_eager": 1},
+    {"fwd_stag": 1}, {"fwd_stag": 2}, {"fwd_stag": 3}, {"fwd_kb": 2}, {"fwd_kb": 1}, {"fwd_tpw": 1}, {"fwd_tpw": 2}, {"fwd_eager": 1},
     {"fwd_hs": 1}, {"dq_tpw": 1}, {"dq_tpw": 2}, {"dkdv_tpw": 1}, {"dkdv_tpw": 2}, {"dq_nlf": 1}, {"dq_w4": 1}, {"dq_kt": 2},
     {"dkdv": 4},
 ]
