@@ -672,7 +672,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
         return hipGetLastError();
     };
     // staggered schedule (fwd_mfma_stag_kernel): d = 128, 64-key tiles (three buffers each) or 128-key tiles (two)
-    if constexpr (D == 128 && (KB == 2 || KB == 4) && !PAD) {
+    if constexpr ((D == 128 || D == 64) && (KB == 2 || KB == 4) && !PAD) {
         if (want_stag) {
             smem = (size_t)2 * (KB == 4 ? 2 : 3) * (32 * KB) * D * 2;
             last_arg = option(OPT_FWD_STAG) == 1 ? option(OPT_FWD_ABL) : 0;
@@ -755,7 +755,7 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     // same order).  Option fwd_stag: 1 = staggered with 64-key tiles, 2 = lock step, 3 = staggered with 128-key tiles.
     const int so = option(OPT_FWD_STAG);
     const bool other_sweep = kb || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) || option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
-    if (D == 128 && (so == 3 || (so == 0 && !other_sweep))) return launch_fwd_t<Tag, D, 4>(a, st, true);
+    if ((D == 128 && (so == 3 || (so == 0 && !other_sweep))) || (D == 64 && so == 3)) return launch_fwd_t<Tag, D, 4>(a, st, true);
     const bool stag = D == 128 && so == 1;
     if (stag) return launch_fwd_t<Tag, D, 2>(a, st, true);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
