@@ -675,7 +675,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
     if constexpr ((D == 128 || D == 64) && (KB == 2 || KB == 4) && !PAD) {
         if (want_stag) {
             smem = (size_t)2 * (KB == 4 ? 2 : 3) * (32 * KB) * D * 2;
-            last_arg = option(OPT_FWD_STAG) == 1 ? option(OPT_FWD_ABL) : 0;
+            last_arg = option(OPT_FWD_STAG) != 0 ? option(OPT_FWD_ABL) : 0;   // debug flags only with an explicit fwd_stag
             return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
         }
     }

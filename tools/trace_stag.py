@@ -13,7 +13,7 @@ import flashattention_lab_cuda as ext
 bh, n, d = 256, 4096, 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v = (torch.randn((bh, n, d), device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(3))
-ext.set_option("fwd_stag", 1)
+ext.set_option("fwd_stag", 3 if "--kb4" in sys.argv else 1)
 abl = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--abl=")]
 ext.set_option("fwd_abl", abl[0] if abl else 0)
 print("ablation flags", abl)
