@@ -355,11 +355,13 @@ hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tra
 // lgkmcnt waits fused to each MFMA, P.V and S accumulation chains interleaved.  K and V are triple buffered with the
 // LDS-DMA issued two tiles ahead at even global half-steps g = 2u (K(u+2), V(u+1)) and counted vmcnt waits, so a
 // transfer has four half-steps to land.
-template <typename Tag, int D, bool CAUSAL, int KB>
+template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale, int dbg /* debug ablation flags (option fwd_abl), 0 in production */) {
+                                                               float scale, int dr_dbg /* row length | debug ablation flags (option fwd_abl) << 16 */) {
+    const int dbg = dr_dbg >> 16;
+    const int DR = PAD ? (dr_dbg & 0xffff) : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
     constexpr int TILE_BYTES = BN * D * 2;
     // 64-key tiles: K and V triple buffered, DMA two tiles ahead.  128-key tiles (160 KB of LDS do not hold six of them):
@@ -377,21 +379,21 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int qrow = q0 + 32 * w + r;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * DR;
     const int stag = w >> 2;   // waves 4..7 (the second wave of every SIMD) run one half-step behind
 
-    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
+    const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
     s16x8 qf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, (qrow * D + 16 * ks + 8 * h) * 2);
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, frag_off(qrow, 16 * ks + 8 * h, DR, PAD));
 
     const int kend = CAUSAL ? min(n, q0 + BM) : n;
     const int T = (kend + BN - 1) / BN;                                               // tiles of the workgroup
     const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31) / BN + 1) : T;                  // tiles this wave computes
 
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
-    const int dma_voff = dma_lane_voff<D>(lane, w);
+    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
+    const int dma_voff = dma_lane_voff<D>(lane, w, DR);
     // Issued at the start of global half-step 2u, first read in half-step 2u+4: K(u+2) and V(u+1).  Two tiles of
     // flight time (a 64-key tile is consumed in about a microsecond, less than one trip to L2 / HBM under load).
     // Always issued, so every wave has the same number of DMAs per step and the waits can be counted; tiles past the
@@ -400,11 +402,11 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     auto issue = [&](int u) {
         if (dbg & 4) return;                                   // ablation: no DMA
         if (NBUF == 3) {
-            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 2) % 3) * TILE_BYTES, (u + 2) * BN, dma_voff, w);
-            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + ((u + 1) % 3) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
+            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 2) % 3) * TILE_BYTES, (u + 2) * BN, dma_voff, w, DR);
+            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + ((u + 1) % 3) * TILE_BYTES, (u + 1) * BN, dma_voff, w, DR);
         } else {   // K(u+1), V(u): first read in half-step 2u+2
-            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 1) & 1) * TILE_BYTES, (u + 1) * BN, dma_voff, w);
-            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (u & 1) * TILE_BYTES, u * BN, dma_voff, w);
+            dma_stage_tile<D, BN, 8>(k_rs, Kbuf + ((u + 1) & 1) * TILE_BYTES, (u + 1) * BN, dma_voff, w, DR);
+            dma_stage_tile<D, BN, 8>(v_rs, Vbuf + (u & 1) * TILE_BYTES, u * BN, dma_voff, w, DR);
         }
     };
 
@@ -600,10 +602,10 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
         __syncthreads();
         stamp();
     };
-    dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w);
+    dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w, DR);
     if (NBUF == 3) {
-        dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w);
-        dma_stage_tile<D, BN, 8>(v_rs, Vbuf, 0, dma_voff, w);
+        dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w, DR);
+        dma_stage_tile<D, BN, 8>(v_rs, Vbuf, 0, dma_voff, w, DR);
     }
     dma_wait_all();
     __syncthreads();
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     const float l_tot = l_run + wave_half_swap(l_run);
     if (qrow < n) {
         const float inv = 1.f / l_tot;
-        uint16_t* orow = o + base + (size_t)qrow * D;
+        uint16_t* orow = o + base + (size_t)qrow * DR;
 #pragma unroll
         for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
                 u32x2 pk;
                 pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
                 pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
+                if (PAD && 32 * dvb + 8 * gq + 4 * h >= DR) continue;   // padded columns (DR is a multiple of 8)
                 *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
             }
         if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
@@ -672,11 +675,11 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
         return hipGetLastError();
     };
     // staggered schedule (fwd_mfma_stag_kernel): d = 128, 64-key tiles (three buffers each) or 128-key tiles (two)
-    if constexpr ((D == 128 || D == 64) && (KB == 2 || KB == 4) && !PAD) {
+    if constexpr ((D == 128 || D == 64) && (KB == 2 || KB == 4)) {
         if (want_stag) {
             smem = (size_t)2 * (KB == 4 ? 2 : 3) * (32 * KB) * D * 2;
-            last_arg = option(OPT_FWD_STAG) != 0 ? option(OPT_FWD_ABL) : 0;   // debug flags only with an explicit fwd_stag
-            return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB>);
+            last_arg = (int)a.d | ((option(OPT_FWD_STAG) != 0 ? option(OPT_FWD_ABL) : 0) << 16);   // debug flags only with an explicit fwd_stag
+            return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD>);
         }
     }
     if constexpr (!PAD && D != 256) {   // sweep variants exist for the 64 / 128 tile widths only
@@ -769,8 +772,10 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
         return a.d == 256 ? launch_fwd_t<f16_tag, 256, 2, false>(a, st) : launch_fwd_t<f16_tag, 256, 2, true>(a, st);
     }
     if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
-        if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
-        return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
+        // 128-wide tiles: the staggered kernel, as for d = 128 (fwd_stag = 2: lock step); 64-wide: lock step
+        const bool stag = a.d > 64 && option(OPT_FWD_STAG) != 2 && !small_grid(a.bh, a.n);
+        if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
+        return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
     }
     const bool sweeping = option(OPT_FWD_KB) || (option(OPT_FWD_STAG) & 1) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
                           option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
