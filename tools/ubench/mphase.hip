@@ -6,6 +6,7 @@
 #include <cstdio>
 using namespace fa;
 
+// VARIANT bits: 8 = waves 4-7 stay resident and meet waves 0-3 at a barrier after every phase (idle partner)
 // VARIANT bits: 1 = tiles high in LDS (K at 0, V at 96 KiB like a 3+3 buffer layout) instead of K at 0 / V at 16 KiB
 //               2 = steps ordered P.V block then S block (no interleave)     4 = compiler-managed reads (no asm)
 template <int VARIANT>
@@ -14,7 +15,12 @@ __global__ __launch_bounds__(512, 2) void kreal(float* out, int iters, int zero)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int i = threadIdx.x; i < 6 * TILE / 4; i += 512) reinterpret_cast<int*>(smem)[i] = 0x3c003c00 + (i & 255);
     __syncthreads();
-    if (threadIdx.x >= 256) return;   // one wave per SIMD
+    const bool idle_half = threadIdx.x >= 256;
+    if (!(VARIANT & 8) && idle_half) return;   // one wave per SIMD
+    if ((VARIANT & 8) && idle_half) {
+        for (int it = 0; it < iters; ++it) __syncthreads();
+        return;
+    }
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     char* Kbuf = smem;
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void kreal(float* out, int iters, int zero)
         for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
         asm volatile("s_nop 15\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
         cyc += t1 - t0;
+        if (VARIANT & 8) __syncthreads();
     }
     float s = 0.f;
     for (int t = 0; t < NDV; ++t)
@@ -128,5 +135,6 @@ int main() {
     run<2>("P.V block then S block (no chain interleave)", d);
     run<4>("compiler-managed reads and waits", d);
     run<5>("compiler-managed, tiles spread over 96 KiB", d);
+    run<8>("kernel's matrix phase, partner wave resident and waiting at the barrier", d);
     return 0;
 }
