@@ -182,6 +182,7 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
                     pacc = mfma32<Tag>(oa, vf[ks], pacc);
                 }
                 // dS = P dP' with the 16-bit P that also feeds dV (one rounding of P, shared by both products)
+                if constexpr (std::is_same<Tag, f16_tag>::value) mfma_result_fence(pacc);   // mul_pack<f16> reads pacc from asm
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll

@@ -347,9 +347,10 @@ __global__ __launch_bounds__(256, 1) void bwd_mfma_kernel(const uint16_t* __rest
 
 bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d >= 8 && d <= 256 && d % 8 == 0; }
 
-// workspace: [dq scratch fp32 (bh*n*d)] [nlse (bh*n)] [ndelta (bh*n)]
-size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
-    return sizeof(float) * ((size_t)bh * n * d + 2 * (size_t)bh * n) + 256;
+// workspace: [nlse (bh*n)] [ndelta (bh*n)] [pad to 256 B] [dq scratch fp32 (bh*n*d): single-kernel (atomic) variant only]
+static size_t row_constants_bytes(int64_t bh, int64_t n) { return (sizeof(float) * 2 * (size_t)bh * n + 255) & ~(size_t)255; }
+size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {
+    return row_constants_bytes(bh, n) + (atomic_variant ? sizeof(float) * (size_t)bh * n * d : 0) + 256;
 }
 
 template <typename Tag, int D>
@@ -358,10 +359,11 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     const size_t nel = (size_t)a.bh * a.n * a.d;
     const bool pad = a.d != D || D == 256;   // padded head dims and the 256-wide tiles run the split backward only
     const long long rows = (long long)a.bh * a.n;
-    float* dq_acc = reinterpret_cast<float*>(a.workspace);
-    float* nlse = dq_acc + nel;
+    float* nlse = reinterpret_cast<float*>(a.workspace);
     float* ndelta = nlse + rows;
+    float* dq_acc = reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + row_constants_bytes(a.bh, a.n));
     const bool fused = a.fused_dq != 0 && !pad;
+    if (fused && a.workspace_bytes < bwd_mfma_workspace_bytes(a.bh, a.n, a.d, true)) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     if (fused) {
         e = hipMemsetAsync(dq_acc, 0, nel * sizeof(float), st);

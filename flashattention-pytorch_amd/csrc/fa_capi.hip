@@ -101,6 +101,14 @@ bool use_mfma_bwd(int dtype, int64_t n, int64_t d, double s, std::initializer_li
            fa::bwd_mfma_supported(dtype, d);
 }
 
+// Does an fa3 call with fp8 = 1 take the e4m3 Q/K path?  ONE predicate for fa3_forward and fa3_backward, over arguments
+// that are the same in both calls (the workspace is not: a misaligned one is an error there), so that the backward
+// always differentiates the function the forward evaluated.
+bool fp8_path(int dtype, int64_t n, int64_t d, double s, const void* q, const void* k, const void* v, const void* o) {
+    return fa::fwd_fp8_supported(dtype, d) && scale_ok(s) && g_mode.load() != FA_MODE_F32_GENERIC && slab_ok(n, d) &&
+           aligned16({q, k, v, o});
+}
+
 int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
                  int64_t n, int64_t d, int dtype, int causal, double scale, void* stream) {
     int rc = check_common(who, bh, n, d, dtype, scale);
@@ -251,15 +259,14 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
     // fp8 is a permission to use the e4m3 Q/K path, honoured where that kernel exists (16-bit tensors, d = 128,
     // positive scale); every other shape takes the regular, more accurate path (as the reference quietly skips its
     // rotation for non-power-of-two d, src/fa3/torch/impl.py:60-61).
-    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC &&
-        slab_ok(n, d) && aligned16({q, k, v, o, workspace})) {
+    if (fp8 && fp8_path(dtype, n, d, softmax_scale, q, k, v, o)) {
         int rc = check_common("fa3_forward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
         if (bh == 0 || n == 0) return FA_OK;
         if (!q || !k || !v || !o || !lse) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_forward: null tensor pointer");
         const size_t need = fa3_forward_workspace_bytes(bh, n, d, dtype, 1);
-        if (!workspace || workspace_bytes < need)
-            return fail(FA_ERR_WORKSPACE, "fa3_forward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        if (!workspace || workspace_bytes < need || !aligned16({workspace}))
+            return fail(FA_ERR_WORKSPACE, "fa3_forward: a 16-byte aligned workspace of %zu bytes is needed, %zu given", need, workspace_bytes);
         fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
         hipError_t e = fa::launch_fwd_fp8(a, workspace, reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_forward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
@@ -276,15 +283,14 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
     // fp8: differentiate the function the forward evaluated, i.e. attention of the e4m3-round-tripped Q and K
     // (the reference's fa3_backward does the same, csrc/fa3/fa3_bwd.cu:134-146); the gradients are returned for
     // q, k themselves (straight-through over the rounding).  o and lse then match the recomputed probabilities.
-    if (fp8 && fa::fwd_fp8_supported(dtype, d) && scale_ok(softmax_scale) && g_mode.load() != FA_MODE_F32_GENERIC &&
-        slab_ok(n, d) && aligned16({q, k, workspace}) && bh > 0 && n > 0) {
+    if (fp8 && fp8_path(dtype, n, d, softmax_scale, q, k, v, o) && bh > 0 && n > 0) {
         int rc = check_common("fa3_backward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
         if (!q || !k) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_backward: null tensor pointer");
         const size_t base_need = fa_backward_workspace_bytes(bh, n, d, dtype);
         const size_t need = fa3_backward_workspace_bytes(bh, n, d, dtype, 1);
-        if (!workspace || workspace_bytes < need)
-            return fail(FA_ERR_WORKSPACE, "fa3_backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        if (!workspace || workspace_bytes < need || !aligned16({workspace}))
+            return fail(FA_ERR_WORKSPACE, "fa3_backward: a 16-byte aligned workspace of %zu bytes is needed, %zu given", need, workspace_bytes);
         char* qt = reinterpret_cast<char*>(workspace) + base_need;
         char* kt = qt + (size_t)bh * n * d * 2;
         hipError_t e = fa::launch_fp8_roundtrip(q, k, qt, kt, bh, n, dtype, reinterpret_cast<hipStream_t>(stream));
@@ -305,7 +311,7 @@ size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype,
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype) {
     if (bh <= 0 || n <= 0 || d <= 0) return 256;
     size_t g = fa::bwd_generic_workspace_bytes(bh, n);
-    size_t m = fa::bwd_mfma_supported(dtype, d) ? fa::bwd_mfma_workspace_bytes(bh, n, d) : 0;
+    size_t m = fa::bwd_mfma_supported(dtype, d) ? fa::bwd_mfma_workspace_bytes(bh, n, d, bwd_atomic_variant()) : 0;
     size_t need = g > m ? g : m;
     return (need + 255) & ~(size_t)255;
 }

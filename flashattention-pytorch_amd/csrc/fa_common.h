@@ -70,11 +70,14 @@ template <> __device__ __forceinline__ uint32_t mul_pack<bf16_tag>(uint32_t p, f
     return pack2<bf16_tag>(unpack_lo<bf16_tag>(p) * a, unpack_hi<bf16_tag>(p) * b);
 }
 template <> __device__ __forceinline__ uint32_t mul_pack<f16_tag>(uint32_t p, float a, float b) {
-    // f16 has a packed multiply: round dP' to f16 (11 significant bits, more than bf16 keeps) and multiply in f16
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    const uint32_t ab = pack2<f16_tag>(a, b);
-    const h2_t r = __builtin_bit_cast(h2_t, p) * __builtin_bit_cast(h2_t, ab);
-    return __builtin_bit_cast(uint32_t, r);
+    // f32 multiply of the f16 P by the f32 dP', one rounding to f16 (v_fma_mix: two instructions per pair, no extra
+    // registers).  Rounding dP' = dO V^T - delta to f16 first would overflow at |dP'| > 65504 although dS = P dP'
+    // itself is small (P ~ 1/N).  Inline asm (hipcc does not select the mix forms from source): when a, b are MFMA
+    // results the caller puts mfma_result_fence() on them first — hipcc pads no hazards in front of asm.
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r) : "v"(p), "v"(a), "v"(b));
+    return r;
 }
 
 // ---- MFMA wrappers: 32x32x16, 16-bit inputs, f32 accumulate ----
@@ -176,14 +179,16 @@ template <int N> __device__ __forceinline__ void lds_wait_for(s16x8& x) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
 }
 // wait + MFMA as ONE asm statement (no compiler-inserted s_nop between them, one issue slot less per step).  The
-// caller owns the hazards: nothing reads `c` by VALU within ~20 cycles (the users sit behind a barrier).
+// caller owns the hazards: the last MFMA of a stream is followed by mfma_stream_fence() before anything but a chained
+// MFMA touches the accumulators (hipcc pads nothing around inline asm; tools/mfma_hazard_audit.py checks the .so).
+// `first` writes its destination before it has read every source: early clobber, as LLVM marks these MFMAs.
 #define FA_MFMA_WAIT_IMPL(TAG, OPC)                                                                                     \
     template <int N> struct MfmaWait_##TAG {                                                                            \
         static __device__ __forceinline__ void acc(s16x8 a, s16x8 b, f32x16& c) {                                       \
             asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "n"(N));           \
         }                                                                                                               \
         static __device__ __forceinline__ void first(s16x8 a, s16x8 b, f32x16& c) {                                     \
-            asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b), "n"(N));            \
+            asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b), "n"(N));            \
         }                                                                                                               \
     };
 FA_MFMA_WAIT_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
@@ -191,6 +196,19 @@ FA_MFMA_WAIT_IMPL(f16, "v_mfma_f32_32x32x16_f16")
 template <typename Tag, int N> struct MfmaWait;
 template <int N> struct MfmaWait<bf16_tag, N> : MfmaWait_bf16<N> {};
 template <int N> struct MfmaWait<f16_tag, N> : MfmaWait_f16<N> {};
+// 8-pass XDL result -> VALU read: 12 wait states after the last MFMA of an inline-asm stream (one s_nop, tied to every
+// accumulator the stream wrote so that no reader is scheduled above it)
+template <int NA, int NB> __device__ __forceinline__ void mfma_stream_fence(f32x16 (&a)[NA], f32x16 (&b)[NB]) {
+    static_assert(NA == 4 && (NB == 4 || NB == 2), "operand list is written out for KB = 4 and NDV = 4 | 2");
+    if constexpr (NB == 4)
+        asm volatile("s_nop 11" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else
+        asm volatile("s_nop 11" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+}
+template <int NB> __device__ __forceinline__ void mfma_stream_fence(f32x16 (&a)[2], f32x16 (&b)[NB]) {
+    if constexpr (NB == 4) asm volatile("s_nop 11" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else asm volatile("s_nop 11" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+}
 __device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // ---- LDS-DMA staging of a swizzled tile -----------------------------------------------------------

@@ -577,6 +577,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             // the matrix-phase wave outranks its partner's vector phase (option fwd_hs = 1 turns this off for the A/B)
             if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);
             for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
+            mfma_stream_fence(sacc, oacc);   // the vector phase reads sacc / oacc by VALU right after the barrier
             if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
         }
     };

@@ -64,7 +64,7 @@ hipError_t set_trace_buffer(void* device_ptr);   // debug: phase timestamps of t
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st);
 bool bwd_mfma_supported(int dtype, int64_t d);
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
-size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d);
+size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant);   // fp32 dQ scratch only for the single-kernel variant
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);  // 8-wave dK/dV
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st);   // d > 64: also WRITES nlse / ndelta
 inline bool dq_makes_row_constants(int64_t d) { return d > 64; }

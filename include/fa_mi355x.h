@@ -50,8 +50,10 @@ extern "C" {
 #define FA_DTYPE_BF16 2
 
 /* Which implementation the dispatcher picks (fa_set_kernel_mode): AUTO = MFMA bf16/f16 kernels
- * when dtype is 16-bit and d is a multiple of 8 up to 128 (64 / 128 wide tiles, narrower rows zero-padded in the kernel),
- * exact-f32 MFMA kernels otherwise. */
+ * when dtype is 16-bit and d is a multiple of 8 up to 256 (64 / 128 / 256 wide tiles, narrower rows zero-padded in the
+ * kernel), exact-f32 MFMA kernels otherwise.
+ * The mode and the fa_set_option knobs are PROCESS-GLOBAL tuning state (sweeps, A/B runs): set them before the
+ * streams start working, not concurrently with calls from other threads. */
 #define FA_MODE_AUTO 0
 #define FA_MODE_F32_GENERIC 1
 #define FA_MODE_BWD_ATOMIC 2 /* as AUTO, but the 16-bit backward is the single-kernel variant with float-atomic dQ */
@@ -96,6 +98,8 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */
+/* bytes for the CURRENT kernel mode: two float row constants per query row (+ an fp32 dQ scratch of bh*n*d floats in
+ * FA_MODE_BWD_ATOMIC only); ask again after changing the mode */
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype);
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
