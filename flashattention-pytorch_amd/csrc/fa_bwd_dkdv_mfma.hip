@@ -298,6 +298,8 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+    // option dkdv = 5: the one-wave-per-SIMD stream kernel (fa_bwd_dkdv_w4.hip)
+    if (option(OPT_DKDV) == 5 && bwd_dkdv_w4_supported(a.dtype, a.d)) return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dkdv_t<bf16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 256, true>(a, nlse, ndelta, st);
         return a.d == 256 ? launch_dkdv_t<f16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 256, true>(a, nlse, ndelta, st);

@@ -68,6 +68,9 @@ size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_va
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);  // 8-wave dK/dV
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st);   // d > 64: also WRITES nlse / ndelta
 inline bool dq_makes_row_constants(int64_t d) { return d > 64; }
+// one wave per SIMD, 64 keys per wave, hand-ordered MFMA stream (fa_bwd_dkdv_w4.hip): d = 128
+bool bwd_dkdv_w4_supported(int dtype, int64_t d);
+hipError_t launch_bwd_dkdv_w4(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);
 
 // FA3-style fp8 forward (fa_fwd_fp8.hip): Q/K quantised to e4m3 per 64-row block, S on the fp8 MFMA
 bool fwd_fp8_supported(int dtype, int64_t d);

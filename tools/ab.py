@@ -1,7 +1,7 @@
 """Interleaved A/B of kernel variants in ONE process (cdna guide §5.4 rule 24): per round every variant runs the same
 fwd+bwd; per-kernel HIP-event times are collected by the library's profiler; medians / minima over the rounds.
 
-    python tools/ab.py [--rounds 7] [--causal] [--head-dim 128]
+    python tools/ab.py [--rounds 7] [--causal] [--head-dim 128] [-v "name:opt=val,opt=val" ...]
 """
 import argparse
 import statistics
@@ -26,14 +26,24 @@ def main():
     ap.add_argument("--head-dim", type=int, default=128)
     ap.add_argument("--seqlen", type=int, default=4096)
     ap.add_argument("--bh", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("-v", "--variant", action="append", default=[],
+                    help='"name:opt=val,opt=val" (fa_set_option names); replaces the built-in list, "base" is always first')
     args = ap.parse_args()
+    global VARIANTS
+    if args.variant:
+        VARIANTS = [("base", {})]
+        for spec in args.variant:
+            name, _, opts = spec.partition(":")
+            VARIANTS.append((name, {kv.split("=")[0]: int(kv.split("=")[1]) for kv in opts.split(",") if kv}))
+    keys = list(dict.fromkeys(ALL_KEYS + [k_ for _, o_ in VARIANTS for k_ in o_]))
     d, n, bh = args.head_dim, args.seqlen, args.bh
     g = torch.Generator(device="cuda").manual_seed(0)
-    q, k, v, do = (torch.randn((bh, n, d), device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(4))
+    q, k, v, do = (torch.randn((bh, n, d), device="cuda", dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16, generator=g) for _ in range(4))
     res = {name: {} for name, _ in VARIANTS}
     for rnd in range(args.rounds + 1):
         for name, opts in VARIANTS:
-            for key in ALL_KEYS:
+            for key in keys:
                 ext.set_option(key, opts.get(key, 0))
             ext.profile_enable(True)
             for _ in range(3):
@@ -46,7 +56,7 @@ def main():
                 continue  # warm-up round
             for kname, (cnt, ms) in prof.items():
                 res[name].setdefault(kname, []).append(ms / cnt)
-    for key in ALL_KEYS:
+    for key in keys:
         ext.set_option(key, 0)
     kernels = sorted({kn for r in res.values() for kn in r})
     print(f"bh={bh} N={n} d={d} causal={args.causal} rounds={args.rounds}: median (min) ms per launch")
