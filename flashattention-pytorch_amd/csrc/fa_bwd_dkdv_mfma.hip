@@ -298,8 +298,13 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
 }
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    // option dkdv = 5: the one-wave-per-SIMD stream kernel (fa_bwd_dkdv_w4.hip)
-    if (option(OPT_DKDV) == 5 && bwd_dkdv_w4_supported(a.dtype, a.d)) return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
+    // d = 128: the one-wave-per-SIMD stream kernel (fa_bwd_dkdv_w4.hip) is the default (-13 % non-causal, -8 ... -10 %
+    // causal against the 8-wave kernel below, profiles/r02_dkdv_stream.md); small launches keep the 128-key tiles.
+    // Option dkdv: 5 = always the stream kernel, 8 = the 8-wave kernel.
+    const int dk_opt = option(OPT_DKDV);
+    const bool sweeping = option(OPT_DKDV_KREG) || option(OPT_DKDV_TPW) || option(OPT_DKDV_STG);
+    if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && !small_grid(a.bh, a.n))))
+        return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dkdv_t<bf16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 256, true>(a, nlse, ndelta, st);
         return a.d == 256 ? launch_dkdv_t<f16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 256, true>(a, nlse, ndelta, st);

@@ -3,8 +3,8 @@
 //   dV[key] = sum_q P[q][key] dO[q],   dK[key] = scale * sum_q dS[q][key] Q[q]
 //   P = exp(S - lse), dS = P * (dO V^T - delta)            (csrc/fa2/fa2_bwd.cu:91-104, the dK/dV half)
 //
-// Same products, same orientation ("key on the lane") and the same rounding points as fa_bwd_dkdv_mfma.hip — the
-// results are bitwise the same — but a different machine mapping:
+// Same products and the same orientation ("key on the lane") as fa_bwd_dkdv_mfma.hip; dV is bitwise the same, dK differs
+// in the last bit (dS = P dP' is formed from the f32 P here, from the 16-bit P there).  A different machine mapping:
 //   * workgroup = 4 waves = 256 keys; a wave owns 64 keys (two 32-key blocks) and the whole 512-register file of
 //     its SIMD: dK^T and dV^T of both blocks live in the 256 accumulation registers, V rows in 64 VGPRs.  Every Q / dO
 //     operand fragment read from LDS now feeds TWO MFMAs (one per key block): 0.75 KB of LDS reads per MFMA
@@ -23,24 +23,48 @@
 
 namespace fa {
 
-// MFMA from inline asm with the accumulator pinned to the architectural VGPRs ("+v"): S' and dP' are consumed by VALU
-// code, and in a 512-register kernel hipcc gives every builtin MFMA an AGPR accumulator (v_accvgpr copies around each
-// use).  hipcc pads nothing around asm: every consumer of these accumulators sits at least two MFMAs downstream, and
-// tools/mfma_hazard_audit.py checks the distances in the built code object (hipcc is free to move a tile).
-#define FA_W4_MFMA_IMPL(TAG, OPC)                                                                                       \
-    struct W4Mfma_##TAG {                                                                                               \
-        template <int N> static __device__ __forceinline__ void v_wait(s16x8 a, s16x8 b, f32x16& c) {                   \
-            asm volatile("s_waitcnt lgkmcnt(%3)\n\t" OPC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "n"(N));           \
+// The stream's instructions come from inline asm: ONE statement per operand group = [requests of group g + 2]
+// [counted wait for group g's operands] [group g's first MFMA], so hipcc neither re-orders them nor pads the seams
+// between them (it puts an s_nop after every asm statement whose outputs the next one reads).  Accumulators: "v" = pinned
+// to the architectural VGPRs (S', dP': consumed by VALU code; in a 512-register kernel hipcc would give a builtin MFMA
+// an AGPR accumulator and copy it around every use), "a" = accumulation registers (dK^T, dV^T: resident).
+// hipcc pads nothing around asm: every consumer of an accumulator sits at least two MFMAs downstream of its last
+// MFMA, and tools/mfma_hazard_audit.py checks the distances in the built code object (hipcc is free to move a tile).
+#define FA_W4_STREAM_IMPL(TAG, OPC)                                                                                     \
+    struct W4Stream_##TAG {                                                                                             \
+        /* request kinds: A = Q rows + K rows of both key blocks, B = one row fragment, T = two transposed 4-row blocks */ \
+        template <int N> static __device__ __forceinline__ void fa_v(unsigned qa, unsigned ka, s16x8& r0, s16x8& r1, s16x8& r2, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:8192\n\ts_waitcnt lgkmcnt(%8)\n\t" OPC " %3, %6, %7, %3" \
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "+v"(c) : "v"(qa), "v"(ka), "v"(a), "v"(b), "n"(N));          \
+        }                                                                                                               \
+        template <int N> static __device__ __forceinline__ void fa_a(unsigned qa, unsigned ka, s16x8& r0, s16x8& r1, s16x8& r2, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:8192\n\ts_waitcnt lgkmcnt(%8)\n\t" OPC " %3, %6, %7, %3" \
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "+a"(c) : "v"(qa), "v"(ka), "v"(a), "v"(b), "n"(N));          \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void fb_v(unsigned qa, s16x8& r0, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\ts_waitcnt lgkmcnt(%6)\n\t" OPC " %1, %3, %4, %1"             \
+                         : "=&v"(r0), "+v"(c) : "v"(qa), "v"(a), "v"(b), "n"(OFF), "n"(N));                             \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void ft_v(unsigned lo_a, unsigned hi_a, s16x4& lo, s16x4& hi, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\ts_waitcnt lgkmcnt(%8)\n\t" OPC " %2, %5, %6, %2" \
+                         : "=&v"(lo), "=&v"(hi), "+v"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "v"(b), "n"(OFF), "n"(N));     \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void ft_a(unsigned lo_a, unsigned hi_a, s16x4& lo, s16x4& hi, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\ts_waitcnt lgkmcnt(%8)\n\t" OPC " %2, %5, %6, %2" \
+                         : "=&v"(lo), "=&v"(hi), "+a"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "v"(b), "n"(OFF), "n"(N));     \
         }                                                                                                               \
         static __device__ __forceinline__ void v(s16x8 a, s16x8 b, f32x16& c) {                                         \
             asm volatile(OPC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));                                             \
         }                                                                                                               \
+        static __device__ __forceinline__ void a(s16x8 a_, s16x8 b, f32x16& c) {                                        \
+            asm volatile(OPC " %0, %1, %2, %0" : "+a"(c) : "v"(a_), "v"(b));                                            \
+        }                                                                                                               \
     };
-FA_W4_MFMA_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
-FA_W4_MFMA_IMPL(f16, "v_mfma_f32_32x32x16_f16")
-template <typename Tag> struct W4Mfma;
-template <> struct W4Mfma<bf16_tag> : W4Mfma_bf16 {};
-template <> struct W4Mfma<f16_tag> : W4Mfma_f16 {};
+FA_W4_STREAM_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
+FA_W4_STREAM_IMPL(f16, "v_mfma_f32_32x32x16_f16")
+template <typename Tag> struct W4Stream;
+template <> struct W4Stream<bf16_tag> : W4Stream_bf16 {};
+template <> struct W4Stream<f16_tag> : W4Stream_f16 {};
 
 // Row constants as initial accumulators: four broadcast reads of 4 floats (registers 4g .. 4g+3 <- floats 8g .. 8g+3
 // past addr).  Compiler-visible loads: hipcc waits for them itself before the chain's first MFMA.
@@ -53,7 +77,24 @@ template <int OFF> __device__ __forceinline__ void lds_acc_init(unsigned addr, f
     }
 }
 
-template <typename Tag, bool CAUSAL>
+// ABL != 0: profiling ablations (wrong results on purpose; option dkdv_abl):
+//   bit 0: no vector slices (P, dS)   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no LDS operand requests
+//   bit 3: no row-constant loads      bit 4: no address updates
+//   bit 5: shader-clock stamps around the block loop; wave 0 of workgroup 0 overwrites dk[0..7] with
+//          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py)
+// LDS-DMA pieces of the stream: the LDS address and the soffset come from scalar arithmetic on kernel arguments and the
+// block counter (no v_readfirstlane feeds them), so the one wait state M0 needs is all the padding there is
+// (fa_common.h's dma16_issue carries the five states a VALU-written SGPR operand would need).
+__device__ __forceinline__ void dma16_issue_s(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                 :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4_issue_s(rsrc_s_t rsrc, unsigned lds_dst, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, %3 offen lds"
+                 :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1)>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -61,35 +102,46 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
                                                              uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
                                                              float scale) {
-    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = 12;
+    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = 16;
+    // operand groups requested ahead of use (6 MFMAs).  4 live groups x 3 fragments = 12 ring slots; with 16 a request
+    // never lands on a fragment the two MFMAs just issued are still reading (hipcc would pad that hazard with an s_nop)
+    constexpr int AHEAD = 3;
     constexpr int K_BYTES = BK * D * 2;          // 64 KiB: the workgroup's K rows (B operand of S)
     constexpr int QT = BQ * D * 2;               // 8 KiB: one 32-row tile of Q (or dO)
-    constexpr int BUF = 2 * QT + 512;            // Q | dO | 64 x -lse/scale | 64 x -delta   (the constants use 32 of the 64)
-    using M = W4Mfma<Tag>;
+    constexpr int BUF = 2 * QT + 1024;           // Q | dO | 64 x -lse/scale | 64 x -delta | 2 x 64 unused (see dma_piece)
+    using M = W4Stream<Tag>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Bs = smem + K_BYTES;                   // [NBUF][BUF]: tile t in buffer t % NBUF
 
+    // A workgroup works through TPW key tiles of one (b,h).  Under the causal mask the pair is heavy + light
+    // (tiles jp and nkt-1-jp): every workgroup then carries the same number of query blocks (as fa_bwd_dkdv_mfma.hip).
+    const int npair = (nkt + TPW - 1) / TPW;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nkt;
-    const int kt = L - bh * nkt;                 // key tile; under the causal mask tile 0 is the heaviest and goes first
-    const int key0 = kt * BK;
+    const int bh = L / npair;
+    const int jp = L - bh * npair;
+    auto tile_of = [&](int ip) -> int {
+        if (TPW == 1) return jp;
+        const int t = CAUSAL ? (ip == 0 ? jp : nkt - 1 - jp) : TPW * jp + ip;
+        if (CAUSAL && ip > 0 && t <= jp) return -1;   // odd tile count: the middle tile is its own pair
+        return t < nkt ? t : -1;
+    };
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const size_t base = (size_t)bh * n * D;
     const size_t rbase = (size_t)bh * n;
-    const int kw0 = key0 + 64 * w;               // first key of this wave
+    int key0 = 0, kw0 = 0;                       // first key of the current tile / of this wave in it
 
     const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
     const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * D * 2);
     const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * D * 2);
     const rsrc_s_t l_rs = make_rsrc_s(nlse + rbase, (unsigned)n * 4);
     const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
+    const rsrc_s_t lr_rs = (w & 1) ? d_rs : l_rs;   // this wave's row-constant source (wave-uniform select)
     const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, D);
 
-    const int qs_first = CAUSAL ? key0 : 0;      // earlier queries see none of this workgroup's keys
-    const int nblk = (n - qs_first + BQ - 1) / BQ;
+    int qs_first = 0, nblk = 0;                  // first query of the current tile's sweep, 32-query blocks in it
     const unsigned bbase = lds_addr_of(Bs);
     // one LDS-DMA piece (1 KiB = 4 rows) of tile t: J = 0, 1 -> Q, J = 2, 3 -> dO, J = 4 -> the wave's row constants
     auto dma_piece = [&](auto jc, int t) {
@@ -98,80 +150,32 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         const unsigned b = bbase + (t & (NBUF - 1)) * BUF;
         if constexpr (J < 4) {
             const int pc = w + 4 * (J & 1);
-            dma16_issue(J < 2 ? q_rs : o_rs, b + (J < 2 ? 0 : QT) + pc * 1024, dma_voff,
-                        __builtin_amdgcn_readfirstlane((qs + 4 * pc) * 2 * D));
+            dma16_issue_s(J < 2 ? q_rs : o_rs, b + (J < 2 ? 0 : QT) + pc * 1024, dma_voff, (qs + 4 * pc) * 2 * D);
         } else {
-            // 64 floats each (rows qs .. qs+63; the second half is never read); rows >= n read as 0: harmless, their dO is 0
-            if (w == 0) dma4_issue(l_rs, b + 2 * QT, lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
-            if (w == 1) dma4_issue(d_rs, b + 2 * QT + 256, lane * 4, __builtin_amdgcn_readfirstlane(qs * 4));
+            // row constants, 64 floats per piece (rows qs .. qs+63; the second half is never read); rows >= n read as 0:
+            // harmless, their dO is 0.  Waves 0 / 1 bring -lse/scale / -delta; waves 2 / 3 issue the same pieces into an
+            // unused area: the stream must not branch (hipcc sinks vector work across a branch, out of its MFMA gap) and
+            // every wave then has the same number of pieces in flight for the counted waits.
+            dma4_issue_s(lr_rs, b + 2 * QT + 256 * w, lane * 4, qs * 4);
         }
     };
     auto stage = [&](int t) { for_each_const([&](auto jc) { dma_piece(jc, t); }, std::make_integer_sequence<int, 5>{}); };
-    // all but this wave's newest tile (4 pieces, + 1 row-constant piece on waves 0 and 1) have landed
-    auto wait_tiles = [&]() {
-        if (w < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    };
+    // all but this wave's newest tile (4 pieces + 1 row-constant piece) have landed
+    auto wait_tiles = [&]() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); };
 
-    // ---- prologue: K tile, V fragments (B operand of dP = dO V^T), tiles 0 .. 2
-    dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, dma_voff, w);
     s16x8 vf[2][NKS];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[kb][ks] = buf_load_frag(v_rs, frag_off(kw0 + 32 * kb + r, 16 * ks + 8 * h, D, false));
-    stage(0);
-    stage(1);
-    stage(2);
-
     f32x16 dka[2][NDB], dva[2][NDB];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int t = 0; t < NDB; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { dka[kb][t][i] = 0.f; dva[kb][t][i] = 0.f; }
-
-    // lane-constant operand addresses (LDS bytes).  Q / dO rows and K rows: row r, chunk 2 ks + h; transposed reads:
-    // 4-row blocks at rows 4 h + tq (+8), chunks 4 db + 2 g16 + (tp >> 1); everything else is an immediate offset
-    // (the swizzle depends on the row modulo 16 only).  The tile addresses move from buffer to buffer during the stream.
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     unsigned kaddr[NKS], qaddr[NKS], tlo[NDB], thi[NDB], laddr;
     // first block this wave computes: earlier ones hold only queries before its first key (causal)
     const int fb = CAUSAL ? 2 * w : 0;
-    {
-        const unsigned kbase = lds_addr_of(Ks) + 64 * w * 2 * D, b0 = bbase + (fb & (NBUF - 1)) * BUF;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int off = TileSwz<D>::off(r, 2 * ks + h);
-            kaddr[ks] = kbase + off;
-            qaddr[ks] = b0 + off;
-        }
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            const int ch = 4 * db + 2 * g16 + (tp >> 1);
-            tlo[db] = b0 + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
-            thi[db] = b0 + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
-        }
-        laddr = b0 + 2 * QT + 16 * h;
-    }
-
-    dma_wait_all();
-    __syncthreads();
-    // the V fragments are first used inside the stream: make hipcc wait for them here, not in the loop (its vmcnt wait
-    // there would also drain the LDS-DMA of the tiles in flight)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ks += 4)
-            asm volatile("" : "+v"(vf[kb][ks]), "+v"(vf[kb][ks + 1]), "+v"(vf[kb][ks + 2]), "+v"(vf[kb][ks + 3]));
-
+    unsigned stamp_cycles = 0;
     // ---- the stream.  Operand groups g = 0 .. 31 of a block, two MFMAs each (key block 0, then 1):
     //   g =  0 ..  7  S'[kb]  += Q[ks] K[kb][ks]          reads: Q rows, K rows of block 0, K rows of block 1
     //   g =  8 .. 15  dP'[kb] += dO[ks] V[kb][ks]         reads: dO rows                    (V in registers)
     //   g = 16 .. 23  dV^T[kb][db] += dO^T[s][db] P[kb][s]    reads: two transposed 4-row blocks of dO
     //   g = 24 .. 31  dK^T[kb][db] += Q^T[s][db] dS[kb][s]    reads: two transposed 4-row blocks of Q
-    // Group g + 2 is requested right before group g's MFMAs; groups 32, 33 are groups 0, 1 of the next block.
+    // Group g + 3 is requested right before group g's MFMAs; groups 32 .. 34 are groups 0 .. 2 of the next block.
     s16x8 ring[RS];
     f32x16 sacc[2], pacc[2];
     u32x4 pp[2][2], sp[2][2];
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         constexpr int g = decltype(gc)::value % 32, ph = g / 8, i = g % 8, s0 = G::slot(g);
         if constexpr (ph == 0) {
             ring[s0] = lds_b128_asm<0>(qaddr[i]);
-            ring[s0 + 1] = lds_b128_asm<0>(kaddr[i]);
-            ring[s0 + 2] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
+            ring[(s0 + 1) % RS] = lds_b128_asm<0>(kaddr[i]);
+            ring[(s0 + 2) % RS] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
         } else if constexpr (ph == 1) {
             ring[s0] = lds_b128_asm<QT>(qaddr[i]);
         } else {
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     };
 
     // Mask (diagonal blocks under the causal mask, keys past n): applied to the INITIAL accumulator of S' — a masked
-    // element starts at -1e30, so P = exp2(c S') = 0 and dS = 0 — right after the row constants are loaded, in a short
-    // wave-uniform branch.  The stream itself has one form: two copies of it under a branch cost hipcc's register
-    // allocator 1.1 KB of spills.  Register i holds query qs + 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2); it is masked
+    // element starts at -1e30, so P = exp2(c S') = 0 and dS = 0 — in a short wave-uniform branch between two blocks.
+    // The stream itself has one form and no branch: two copies of it cost hipcc's register allocator 1.1 KB of spills,
+    // and across a branch inside it hipcc sinks vector work out of its MFMA gap to the first use.  Register i holds query qs + 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2); it is masked
     // when it precedes this lane's key (causal) or the key lies past n: rc(i) < thr, one per-lane threshold per key block.
     auto mask_init = [&](int blk) {   // blk: the block whose initial accumulators were just requested
         const int qs = qs_first + BQ * blk;
@@ -216,68 +220,157 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     };
     auto block = [&](int blk) {
         const int dlt = ((blk + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
-        auto PU = [&](auto kbc, auto mc) {   // P pair: elements 2m, 2m+1 of S'[kb] -> exp2 -> one packed dword
-            constexpr int kb = decltype(kbc)::value, m = decltype(mc)::value;
-            const float p0 = __builtin_amdgcn_exp2f(sacc[kb][2 * m] * c_log2), p1 = __builtin_amdgcn_exp2f(sacc[kb][2 * m + 1] * c_log2);
-            pp[kb][m >> 2][m & 3] = pack2<Tag>(p0, p1);
+        // Vector work, cut to fit the MFMA gaps (an MFMA leaves ~24 of its 32 cycles of vector issue to the wave; prices
+        // in MI355X_MICROARCH.md: v_exp 8, the rest 4).  PE: one element of S' -> exp2 (2 instructions);  PC: one packed
+        // dword of P from two finished elements (placed one gap after its exp2's: no dependency stall, no hazard nop);
+        // SU: one packed dword of dS = P dP' (f32 P, one rounding).
+        auto PE = [&](auto kbc, auto ic) {   // in place: the f32 P is what dS is made from (as in the dQ kernel)
+            constexpr int kb = decltype(kbc)::value, i = decltype(ic)::value;
+            sacc[kb][i] = __builtin_amdgcn_exp2f(sacc[kb][i] * c_log2);
         };
-        auto SU = [&](auto kbc, auto mc) {   // dS pair = P dP' with the 16-bit P that also feeds dV
+        auto PC = [&](auto kbc, auto mc) {
             constexpr int kb = decltype(kbc)::value, m = decltype(mc)::value;
-            sp[kb][m >> 2][m & 3] = mul_pack<Tag>(pp[kb][m >> 2][m & 3], pacc[kb][2 * m], pacc[kb][2 * m + 1]);
+            pp[kb][m >> 2][m & 3] = pack2<Tag>(sacc[kb][2 * m], sacc[kb][2 * m + 1]);
+        };
+        auto SU = [&](auto kbc, auto mc) {
+            constexpr int kb = decltype(kbc)::value, m = decltype(mc)::value;
+            sp[kb][m >> 2][m & 3] = pack2<Tag>(sacc[kb][2 * m] * pacc[kb][2 * m], sacc[kb][2 * m + 1] * pacc[kb][2 * m + 1]);
         };
         using std::integral_constant;
-        auto slice = [&](auto sc) {          // the vector work that follows MFMA S of the block (S = 0 .. 63)
+        // The vector work that follows MFMA S of the block (S = 0 .. 63).  Deadlines: P[kb][s] feeds MFMAs 32 + 8 s ...,
+        // dS[kb][s] feeds MFMAs 48 + 8 s ...; S' is complete after MFMA 15, dP' after MFMA 31, and a consumer sits at
+        // least two MFMAs behind the chain it reads (hipcc pads nothing around the asm MFMAs).
+        auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr (S >= 17 && S <= 24) PU(integral_constant<int, 0>{}, integral_constant<int, S - 17>{});
-            else if constexpr (S >= 25 && S <= 32) PU(integral_constant<int, 1>{}, integral_constant<int, S - 25>{});
-            else if constexpr (S >= 33 && S <= 36) {
-                SU(integral_constant<int, 0>{}, integral_constant<int, 2 * (S - 33)>{});
-                SU(integral_constant<int, 0>{}, integral_constant<int, 2 * (S - 33) + 1>{});
-            } else if constexpr (S >= 37 && S <= 40) {
-                SU(integral_constant<int, 1>{}, integral_constant<int, 2 * (S - 37)>{});
-                SU(integral_constant<int, 1>{}, integral_constant<int, 2 * (S - 37) + 1>{});
-            } else if constexpr (S == 41) laddr += dlt;
-            // the next block's row constants become the initial accumulators (S' and dP' are free by now)
-            else if constexpr (S == 42) lds_acc_init<0>(laddr, sacc[0]);
-            else if constexpr (S == 43) { lds_acc_init<0>(laddr, sacc[1]); mask_init(blk + 1); }
-            else if constexpr (S == 44) lds_acc_init<256>(laddr, pacc[0]);
-            else if constexpr (S == 45) lds_acc_init<256>(laddr, pacc[1]);
-            else if constexpr (S >= 46 && S <= 50) {
-                dma_piece(integral_constant<int, S - 46>{}, blk + 3);
+            if constexpr ((ABL & 1) && S >= 17 && S <= 48) {}
+            else if constexpr ((ABL & 2) && S >= 53 && S <= 57) {}
+            else if constexpr ((ABL & 8) && S >= 49 && S <= 52) {}
+            else if constexpr ((ABL & 16) && (S == 48 || S >= 53)) {}
+            else if constexpr (S >= 17 && S <= 33) {
+                // pair u = S - 17 (kb = u / 8, m = u % 8): its two exp2's; the pack of pair u - 1 goes first
+                constexpr int u = S - 17;
+                if constexpr (u >= 1) PC(integral_constant<int, (u - 1) / 8>{}, integral_constant<int, (u - 1) % 8>{});
+                if constexpr (u < 16) {
+                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8)>{});
+                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8) + 1>{});
+                }
+                if constexpr (S == 33) SU(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            }
+            // one dS dword per gap: key block 0 / 1 of k-step s = 0 (MFMAs 48 ...), then of s = 1 (MFMAs 56 ...)
+            else if constexpr (S >= 34 && S <= 36) SU(integral_constant<int, 0>{}, integral_constant<int, S - 33>{});
+            else if constexpr (S >= 37 && S <= 40) SU(integral_constant<int, 1>{}, integral_constant<int, S - 37>{});
+            else if constexpr (S >= 41 && S <= 44) SU(integral_constant<int, 0>{}, integral_constant<int, S - 37>{});
+            else if constexpr (S >= 45 && S <= 48) {
+                SU(integral_constant<int, 1>{}, integral_constant<int, S - 41>{});
+                if constexpr (S == 48) laddr += dlt;
+            }
+            // the next block's row constants become the initial accumulators (S' / P and dP' are free after MFMA 48)
+            else if constexpr (S == 49) lds_acc_init<0>(laddr, sacc[0]);
+            else if constexpr (S == 50) lds_acc_init<0>(laddr, sacc[1]);
+            else if constexpr (S == 51) lds_acc_init<256>(laddr, pacc[0]);
+            else if constexpr (S == 52) lds_acc_init<256>(laddr, pacc[1]);
+            else if constexpr (S >= 53 && S <= 57) {
+                dma_piece(integral_constant<int, S - 53>{}, blk + 3);
+                qaddr[S - 53] += dlt;                                   // dO rows were last requested at MFMA 24
+                if constexpr (S >= 55) qaddr[S - 50] += dlt;            // 5, 6, 7
+            } else if constexpr (S == 59) {
                 // hipcc waits for its row-constant loads at their first use: give it one here, where few operand requests
                 // are in flight, instead of the head of the next block's chains (its wait drains our requests too)
-                if constexpr (S == 50) asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(pacc[0]), "+v"(pacc[1]));
-            }
-            else if constexpr (S >= 51 && S <= 58) qaddr[S - 51] += dlt;   // dO rows were last requested at MFMA 26
-            else if constexpr (S >= 60) { tlo[S - 60] += dlt; thi[S - 60] += dlt; }   // last transposed request: MFMA 58
+                asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(pacc[0]), "+v"(pacc[1]));
+            } else if constexpr (S >= 60) { tlo[S - 60] += dlt; thi[S - 60] += dlt; }   // last transposed request: MFMA 56
         };
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value, ph = g / 8, i = g % 8, s0 = G::slot(g);
-            constexpr int NWAIT = G::reads(g + 1) + G::reads(g + 2);
-            fetch(integral_constant<int, g + 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ph == 0) M::template v_wait<NWAIT>(ring[s0], ring[s0 + 1], sacc[0]);
-            else if constexpr (ph == 1) M::template v_wait<NWAIT>(ring[s0], vf[0][i], pacc[0]);
-            else {
-                // resident accumulators: compiler-visible MFMAs (hipcc keeps them in the accumulation registers and pads
-                // their hazards); the operand wait is ours, the requests came from asm
-                lds_wait_for<NWAIT>(ring[s0]);
-                if constexpr (ph == 2) dva[0][i % 4] = mfma32<Tag>(ring[s0], *reinterpret_cast<s16x8*>(&pp[0][i / 4]), dva[0][i % 4]);
-                else dka[0][i % 4] = mfma32<Tag>(ring[s0], *reinterpret_cast<s16x8*>(&sp[0][i / 4]), dka[0][i % 4]);
+            constexpr int NWAIT = G::reads(g + 1) + G::reads(g + 2) + G::reads(g + 3);
+            constexpr int g2 = (g + AHEAD) % 32, ph2 = g2 / 8, i2 = g2 % 8, t0 = G::slot(g2);   // the group requested here
+            // first operand of the MFMAs, second operand / accumulator of key block 0 and 1
+            const s16x8 opa = ring[s0];
+            s16x8 opb0, opb1;
+            if constexpr (ph == 0) { opb0 = ring[(s0 + 1) % RS]; opb1 = ring[(s0 + 2) % RS]; }
+            else if constexpr (ph == 1) { opb0 = vf[0][i]; opb1 = vf[1][i]; }
+            else if constexpr (ph == 2) { opb0 = *reinterpret_cast<s16x8*>(&pp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&pp[1][i / 4]); }
+            else { opb0 = *reinterpret_cast<s16x8*>(&sp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&sp[1][i / 4]); }
+            f32x16& acc0 = ph == 0 ? sacc[0] : (ph == 1 ? pacc[0] : (ph == 2 ? dva[0][i % 4] : dka[0][i % 4]));
+            f32x16& acc1 = ph == 0 ? sacc[1] : (ph == 1 ? pacc[1] : (ph == 2 ? dva[1][i % 4] : dka[1][i % 4]));
+            if constexpr (ABL & 4) {
+                if constexpr (ph < 2) M::v(opa, opb0, acc0);
+                else M::a(opa, opb0, acc0);
+            } else if constexpr (ph2 == 0) {
+                if constexpr (ph < 2) M::template fa_v<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], ring[(t0 + 2) % RS], opa, opb0, acc0);
+                else M::template fa_a<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], ring[(t0 + 2) % RS], opa, opb0, acc0);
+            } else if constexpr (ph2 == 1) {
+                static_assert(ph < 2, "dO rows are requested during the S' and dP' chains");
+                M::template fb_v<NWAIT, QT>(qaddr[i2], ring[t0], opa, opb0, acc0);
+            } else {
+                constexpr int off = (ph2 == 2 ? QT : 0) + (i2 / 4) * 16 * 2 * D;
+                s16x4 lo, hi;
+                if constexpr (ph < 2) M::template ft_v<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, acc0);
+                else M::template ft_a<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, acc0);
+                ring[t0] = cat8(lo, hi);
             }
             __builtin_amdgcn_sched_barrier(0);
             slice(integral_constant<int, 2 * g>{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ph == 0) M::v(ring[s0], ring[s0 + 2], sacc[1]);
-            else if constexpr (ph == 1) M::v(ring[s0], vf[1][i], pacc[1]);
-            else if constexpr (ph == 2) dva[1][i % 4] = mfma32<Tag>(ring[s0], *reinterpret_cast<s16x8*>(&pp[1][i / 4]), dva[1][i % 4]);
-            else dka[1][i % 4] = mfma32<Tag>(ring[s0], *reinterpret_cast<s16x8*>(&sp[1][i / 4]), dka[1][i % 4]);
+            if constexpr (ph < 2) M::v(opa, opb1, acc1);
+            else M::a(opa, opb1, acc1);
             __builtin_amdgcn_sched_barrier(0);
             slice(integral_constant<int, 2 * g + 1>{});
             __builtin_amdgcn_sched_barrier(0);
         };
         for_each_const(group, std::make_integer_sequence<int, 32>{});
     };
+
+#pragma unroll 1
+    for (int ip = 0; ip < TPW; ++ip) {
+    const int kt = tile_of(ip);
+    if (TPW > 1 && kt < 0) break;
+    key0 = kt * BK;
+    kw0 = key0 + 64 * w;
+    qs_first = CAUSAL ? key0 : 0;                // earlier queries see none of this tile's keys
+    nblk = (n - qs_first + BQ - 1) / BQ;
+    // ---- prologue of a key tile: K tile, V fragments (B operand of dP = dO V^T), query tiles 0 .. 2
+    dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, dma_voff, w);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) vf[kb][ks] = buf_load_frag(v_rs, frag_off(kw0 + 32 * kb + r, 16 * ks + 8 * h, D, false));
+    stage(0);
+    stage(1);
+    stage(2);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < NDB; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dka[kb][t][i] = 0.f; dva[kb][t][i] = 0.f; }
+    // lane-constant operand addresses (LDS bytes).  Q / dO rows and K rows: row r, chunk 2 ks + h; transposed reads:
+    // 4-row blocks at rows 4 h + tq (+8), chunks 4 db + 2 g16 + (tp >> 1); everything else is an immediate offset
+    // (the swizzle depends on the row modulo 16 only).  The tile addresses move from buffer to buffer during the stream.
+    {
+        const unsigned kbase = lds_addr_of(Ks) + 64 * w * 2 * D, b0 = bbase + (fb & (NBUF - 1)) * BUF;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int off = TileSwz<D>::off(r, 2 * ks + h);
+            kaddr[ks] = kbase + off;
+            qaddr[ks] = b0 + off;
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int ch = 4 * db + 2 * g16 + (tp >> 1);
+            tlo[db] = b0 + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
+            thi[db] = b0 + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
+        }
+        laddr = b0 + 2 * QT + 16 * h;
+    }
+    dma_wait_all();
+    __syncthreads();
+    // the V fragments are first used inside the stream: make hipcc wait for them here, not in the loop (its vmcnt wait
+    // there would also drain the LDS-DMA of the tiles in flight)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks += 4)
+            asm volatile("" : "+v"(vf[kb][ks]), "+v"(vf[kb][ks + 1]), "+v"(vf[kb][ks + 2]), "+v"(vf[kb][ks + 3]));
 
     // feed-only blocks (causal: queries before this wave's first key): the wave's share of the LDS-DMA and the barriers
     for (int blk = 0; blk < min(fb, nblk); ++blk) {
@@ -295,16 +388,32 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         lds_acc_init<256>(laddr, pacc[1]);
         fetch(std::integral_constant<int, 0>{});
         fetch(std::integral_constant<int, 1>{});
+        fetch(std::integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t_begin = 0;
+        if (ABL & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
 #pragma unroll 1
         for (int blk = fb; blk < nblk; ++blk) {
             block(blk);
-            wait_tiles();
-            __builtin_amdgcn_s_barrier();
+            mask_init(blk + 1);   // on the next block's initial accumulators, outside the stream (the only branch)
+            if (!(ABL & 2)) {
+                wait_tiles();
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (ABL & 32) {
+            unsigned long long t_end;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+            stamp_cycles = (unsigned)(t_end - t_begin);
         }
     }
 
-    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV
+    // ---- epilogue: dK = scale * dK^T (transposed back on the store), dV.  The resident accumulators were last
+    // written from asm: pad the MFMA -> accumulator read hazard by hand, then everything below is compiler-visible.
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+a"(dka[0][0]), "+a"(dka[0][1]), "+a"(dka[0][2]), "+a"(dka[0][3]), "+a"(dka[1][0]), "+a"(dka[1][1]),
+                   "+a"(dka[1][2]), "+a"(dka[1][3]), "+a"(dva[0][0]), "+a"(dva[0][1]), "+a"(dva[0][2]), "+a"(dva[0][3]),
+                   "+a"(dva[1][0]), "+a"(dva[1][1]), "+a"(dva[1][2]), "+a"(dva[1][3]));
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     // a wave only ever read its own 64 K rows: that slice of the K tile is its staging area for whole-row stores
     char* stg = Ks + w * 64 * D * 2;
@@ -328,15 +437,25 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             }
         store_rows_via_lds<D>(stg + 32 * D * 2, vals, dv + base, kw0 + 32 * kb, n, lane, D);
     }
+    if (TPW > 1) __syncthreads();   // the K tile and the query-tile buffers are about to be refilled
+    }   // key tiles of this workgroup
+    if ((ABL & 32) && L == 0 && w == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            reinterpret_cast<unsigned*>(dk)[0] = stamp_cycles;
+            reinterpret_cast<unsigned*>(dk)[1] = (unsigned)(nblk - fb);
+        }
+    }
 }
 
 template <typename Tag>
 static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     constexpr int D = 128, BK = 256;
     const int nkt = (int)((a.n + BK - 1) / BK);
-    const size_t smem = (size_t)BK * D * 2 + 4 * (2 * 32 * D * 2 + 512);
+    const size_t smem = (size_t)BK * D * 2 + 4 * (2 * 32 * D * 2 + 1024);
     const float c = a.scale * 1.4426950408889634f;
-    dim3 grid((unsigned)(nkt * a.bh));
+    // key tiles per workgroup: 2 under the causal mask (heavy + light pair), else 1
+    dim3 grid((unsigned)((a.causal ? (nkt + 1) / 2 : nkt) * a.bh));
     ProfScope ps(K_BWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
@@ -345,6 +464,26 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
                            (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
         return hipGetLastError();
     };
+    if constexpr (std::is_same<Tag, bf16_tag>::value) {
+        if (!a.causal) switch (option(OPT_DKDV_ABL)) {   // profiling ablations: see the kernel's header comment
+            case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 1>);
+            case 2: return launch(bwd_dkdv_w4_kernel<Tag, false, 2>);
+            case 4: return launch(bwd_dkdv_w4_kernel<Tag, false, 4>);
+            case 8: return launch(bwd_dkdv_w4_kernel<Tag, false, 8>);
+            case 16: return launch(bwd_dkdv_w4_kernel<Tag, false, 16>);
+            case 3: return launch(bwd_dkdv_w4_kernel<Tag, false, 3>);
+            case 31: return launch(bwd_dkdv_w4_kernel<Tag, false, 31>);
+            case 32: return launch(bwd_dkdv_w4_kernel<Tag, false, 32>);
+            case 33: return launch(bwd_dkdv_w4_kernel<Tag, false, 33>);
+            case 34: return launch(bwd_dkdv_w4_kernel<Tag, false, 34>);
+            case 36: return launch(bwd_dkdv_w4_kernel<Tag, false, 36>);
+            case 40: return launch(bwd_dkdv_w4_kernel<Tag, false, 40>);
+            case 59: return launch(bwd_dkdv_w4_kernel<Tag, false, 59>);
+            case 63: return launch(bwd_dkdv_w4_kernel<Tag, false, 63>);
+            case 27: return launch(bwd_dkdv_w4_kernel<Tag, false, 27>);
+            default: break;
+        }
+    }
     return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true>) : launch(bwd_dkdv_w4_kernel<Tag, false>);
 }
 

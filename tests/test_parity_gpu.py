@@ -377,15 +377,16 @@ def test_backward_variants_agree_and_split_is_deterministic(causal, d, device):
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bh,n", [(3, 1100), (2, 257), (1, 4096), (5, 64), (2, 2048)])
-def test_dkdv_stream_kernel_is_bitwise_the_8wave_kernel(bh, n, dtype, causal, device):
-    """The one-wave-per-SIMD dK/dV kernel (fa_bwd_dkdv_w4.hip, option dkdv=5) performs the 8-wave kernel's operations in
-    the same order with the same rounding points: dK and dV must be bitwise equal (ragged N, diagonal blocks, keys past
-    n, several key tiles)."""
+def test_dkdv_stream_kernel_against_the_8wave_kernel(bh, n, dtype, causal, device):
+    """The one-wave-per-SIMD dK/dV kernel (fa_bwd_dkdv_w4.hip) forms the same P in the same order as the 8-wave kernel:
+    dV must be bitwise equal; dK differs only through the rounding of dS (f32 P x dP' here, 16-bit P x dP' there), i.e.
+    by a few units in the last place (ragged N, diagonal blocks, keys past n, several key tiles)."""
     import flashattention_lab_cuda as ext
 
     q, k, v, do = (t.to(device) for t in make_qkv(bh, n, 128, dtype, seed=500 + n))
     ext.set_option("small_grid", 1)   # the 8-wave tiling on both sides
     try:
+        ext.set_option("dkdv", 8)
         a = _run(2, q, k, v, causal, 128 ** -0.5, do=do)
         ext.set_option("dkdv", 5)
         b = _run(2, q, k, v, causal, 128 ** -0.5, do=do)
@@ -393,13 +394,17 @@ def test_dkdv_stream_kernel_is_bitwise_the_8wave_kernel(bh, n, dtype, causal, de
         ext.set_option("dkdv", 0)
         ext.set_option("small_grid", 0)
     for name, x, y in zip(("o", "lse", "dq", "dk", "dv"), a, b):
-        assert torch.equal(x, y), (name, (x.float() - y.float()).abs().max().item())
+        if name == "dk":
+            tol = 2.0 ** -6 * max(1e-3, x.float().abs().max().item())
+            assert (x.float() - y.float()).abs().max().item() <= tol, (name, (x.float() - y.float()).abs().max().item(), tol)
+        else:
+            assert torch.equal(x, y), (name, (x.float() - y.float()).abs().max().item())
 
 
 FWD_OPTIONS = [
     {"fwd_stag": 1}, {"fwd_stag": 2}, {"fwd_stag": 3}, {"fwd_kb": 2}, {"fwd_kb": 1}, {"fwd_tpw": 1}, {"fwd_tpw": 2}, {"fwd_eager": 1},
     {"fwd_hs": 1}, {"dq_tpw": 1}, {"dq_tpw": 2}, {"dkdv_tpw": 1}, {"dkdv_tpw": 2}, {"dq_nlf": 1}, {"dq_w4": 1}, {"dq_kt": 2},
-    {"dkdv": 4}, {"dkdv": 5},
+    {"dkdv": 4}, {"dkdv": 5}, {"dkdv": 8},
 ]
 
 
