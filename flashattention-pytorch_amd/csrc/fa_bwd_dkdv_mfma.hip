@@ -188,6 +188,8 @@ __global__ __launch_bounds__((D == 256 || W4) ? 256 : 512, D == 256 ? 1 : 2) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         sp[s][j] = mul_pack<Tag>(pp[s][j], pacc[8 * s + 2 * j], pacc[8 * s + 2 * j + 1]);
+                // mul_pack<f16> writes dS from asm: two wait states before an MFMA may read it (hipcc sees no VALU there)
+                if constexpr (std::is_same<Tag, f16_tag>::value) asm volatile("s_nop 1" : "+v"(sp[0]), "+v"(sp[1]));
             }
             if (D > 64) __builtin_amdgcn_sched_barrier(0);
             // ---- dV^T += dO^T P ,  dK^T += Q^T dS   (A operands: transposed reads of the dO / Q tiles)
