@@ -275,6 +275,8 @@ static hipError_t launch_dq_t(const BwdArgs& a, float* nlse, float* ndelta, hipS
 }
 
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
+    // option dq: 5 = the one-wave-per-SIMD stream kernel (fa_bwd_dq_w4.hip), 8 = the 8-wave kernel below
+    if (option(OPT_DQ) == 5 && bwd_dq_w4_supported(a.dtype, a.d)) return launch_bwd_dq_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dq_kt<bf16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 256, 1, true>(a, nlse, ndelta, st);
         return a.d == 256 ? launch_dq_kt<f16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 256, 1, true>(a, nlse, ndelta, st);

@@ -401,10 +401,41 @@ def test_dkdv_stream_kernel_against_the_8wave_kernel(bh, n, dtype, causal, devic
             assert torch.equal(x, y), (name, (x.float() - y.float()).abs().max().item())
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bh,n", [(3, 1100), (2, 257), (1, 4096), (5, 64), (2, 2048), (1, 31)])
+def test_dq_stream_kernel_against_the_8wave_kernel(bh, n, dtype, causal, device):
+    """The one-wave-per-SIMD dQ kernel (fa_bwd_dq_w4.hip) against the 8-wave kernel: the row constants it leaves for the
+    dK/dV pass are made by the same arithmetic (dK, dV bitwise equal), dQ agrees to the rounding of the exp2 argument
+    (-lse enters through an fma there, as the initial accumulator here), and both sit inside the reference's bar against
+    the fp64 oracle (ragged N, diagonal blocks, keys past n, several key tiles, heavy + light pairing)."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = make_qkv(bh, n, 128, dtype, seed=700 + n)
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, 128 ** -0.5, math_dtype=torch.float64)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    ext.set_option("small_grid", 1)   # the 256-row tiling on both sides
+    try:
+        ext.set_option("dq", 8)
+        a = _run(2, qd, kd, vd, causal, 128 ** -0.5, do=dod)
+        ext.set_option("dq", 5)
+        b = _run(2, qd, kd, vd, causal, 128 ** -0.5, do=dod)
+    finally:
+        ext.set_option("dq", 0)
+        ext.set_option("small_grid", 0)
+    for name, x, y in zip(("o", "lse", "dq", "dk", "dv"), a, b):
+        if name == "dq":
+            tol = 2.0 ** -6 * max(1e-3, x.float().abs().max().item())
+            assert (x.float() - y.float()).abs().max().item() <= tol, (name, (x.float() - y.float()).abs().max().item(), tol)
+        else:
+            assert torch.equal(x, y), (name, (x.float() - y.float()).abs().max().item())
+    torch.testing.assert_close(b[2].cpu(), rq, **dtype_tolerances(dtype))
+
+
 FWD_OPTIONS = [
     {"fwd_stag": 1}, {"fwd_stag": 2}, {"fwd_stag": 3}, {"fwd_kb": 2}, {"fwd_kb": 1}, {"fwd_tpw": 1}, {"fwd_tpw": 2}, {"fwd_eager": 1},
     {"fwd_hs": 1}, {"dq_tpw": 1}, {"dq_tpw": 2}, {"dkdv_tpw": 1}, {"dkdv_tpw": 2}, {"dq_nlf": 1}, {"dq_w4": 1}, {"dq_kt": 2},
-    {"dkdv": 4}, {"dkdv": 5}, {"dkdv": 8},
+    {"dkdv": 4}, {"dkdv": 5}, {"dkdv": 8}, {"dq": 5}, {"dq": 8},
 ]
 
 

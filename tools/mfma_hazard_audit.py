@@ -38,8 +38,8 @@ LLVM_BIN = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flashattention-pytorch_amd",
                            "flashattention_lab_cuda", "libfa_mi355x.so")
 
-# profiling-ablation instantiations: bwd_dkdv_w4_kernel<Tag, CAUSAL, ABL != 0, TPW>, fwd_mfma_kernel<..., ABL != 0, W4>
-DEFAULT_SKIP = r"bwd_dkdv_w4_kernelINS_\w+ELb[01]ELi[1-9]|fwd_mfma_kernelINS_\w+?ELi\d+ELb[01]ELi\d+ELb[01]ELb[01]ELb[01]ELi\d+ELb[01]ELi[1-9]"
+# profiling-ablation instantiations: bwd_{dkdv,dq}_w4_kernel<Tag, CAUSAL, ABL != 0, TPW>, fwd_mfma_kernel<..., ABL != 0, W4>
+DEFAULT_SKIP = r"bwd_(dkdv|dq)_w4_kernelINS_\w+ELb[01]ELi[1-9]|fwd_mfma_kernelINS_\w+?ELi\d+ELb[01]ELi\d+ELb[01]ELb[01]ELb[01]ELi\d+ELb[01]ELi[1-9]"
 
 # passes (4 cycles each) of the MFMA shapes this library uses
 PASSES = [
