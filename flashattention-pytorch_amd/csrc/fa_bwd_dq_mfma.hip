@@ -275,8 +275,13 @@ static hipError_t launch_dq_t(const BwdArgs& a, float* nlse, float* ndelta, hipS
 }
 
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
-    // option dq: 5 = the one-wave-per-SIMD stream kernel (fa_bwd_dq_w4.hip), 8 = the 8-wave kernel below
-    if (option(OPT_DQ) == 5 && bwd_dq_w4_supported(a.dtype, a.d)) return launch_bwd_dq_w4(a, nlse, ndelta, st);
+    // d = 128: the one-wave-per-SIMD stream kernel (fa_bwd_dq_w4.hip) is the default (-2.5 % against the 8-wave kernel
+    // below at half the LDS operand traffic, profiles/r02_stream_kernels.md); small launches keep the 128-row tiles.
+    // Option dq: 5 = always the stream kernel, 8 = the 8-wave kernel.
+    const int dq_opt = option(OPT_DQ);
+    const bool sweeping = option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || option(OPT_DQ_W4);
+    if (bwd_dq_w4_supported(a.dtype, a.d) && (dq_opt == 5 || (dq_opt == 0 && !sweeping && !small_grid(a.bh, a.n))))
+        return launch_bwd_dq_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dq_kt<bf16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 256, 1, true>(a, nlse, ndelta, st);
         return a.d == 256 ? launch_dq_kt<f16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<f16_tag, 256, 1, true>(a, nlse, ndelta, st);

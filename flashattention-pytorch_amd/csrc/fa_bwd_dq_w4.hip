@@ -52,6 +52,37 @@ namespace fa {
             asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\ts_waitcnt lgkmcnt(%8)\n\t" OPC " %2, %5, %6, %2" \
                          : "=&v"(lo), "=&v"(hi), "+a"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "v"(b), "n"(OFF), "n"(N));     \
         }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void r_first0(unsigned ad, s16x8& r0, s16x8 a, s16x8 b, f32x16& d) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\ts_waitcnt lgkmcnt(%6)\n\t" OPC " %1, %3, %4, 0"              \
+                         : "=&v"(r0), "=&v"(d) : "v"(ad), "v"(a), "a"(b), "n"(OFF), "n"(N));                            \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void r_first_nw(unsigned ad, s16x8& r0, s16x8 a, s16x8 b, f32x16& d, const f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%6\n\t" OPC " %1, %3, %4, %5"             \
+                         : "=&v"(r0), "=&v"(d) : "v"(ad), "v"(a), "a"(b), "v"(c), "n"(OFF));                     \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void r_acc_nw(unsigned ad, s16x8& r0, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" OPC " %1, %3, %4, %1"             \
+                         : "=&v"(r0), "+v"(c) : "v"(ad), "v"(a), "a"(b), "n"(OFF));                             \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void r_acca_nw(unsigned ad, s16x8& r0, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" OPC " %1, %3, %4, %1"             \
+                         : "=&v"(r0), "+a"(c) : "v"(ad), "v"(a), "v"(b), "n"(OFF));                             \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void t_acc_nw(unsigned lo_a, unsigned hi_a, s16x4& lo, s16x4& hi, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t" OPC " %2, %5, %6, %2" \
+                         : "=&v"(lo), "=&v"(hi), "+v"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "a"(b), "n"(OFF));     \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void t_acca_nw(unsigned lo_a, unsigned hi_a, s16x4& lo, s16x4& hi, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t" OPC " %2, %5, %6, %2" \
+                         : "=&v"(lo), "=&v"(hi), "+a"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "v"(b), "n"(OFF));     \
+        }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void r_first0_nw(unsigned ad, s16x8& r0, s16x8 a, s16x8 b, f32x16& d) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" OPC " %1, %3, %4, 0"              \
+                         : "=&v"(r0), "=&v"(d) : "v"(ad), "v"(a), "a"(b), "n"(OFF));                            \
+        }                                                                                                               \
+        static __device__ __forceinline__ void first0(s16x8 a, s16x8 b, f32x16& d) {                                    \
+            asm volatile(OPC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));                                             \
+        }                                                                                                               \
         static __device__ __forceinline__ void first(s16x8 a, s16x8 b, f32x16& d, const f32x16& c) {                    \
             asm volatile(OPC " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));                                    \
         }                                                                                                               \
@@ -130,10 +161,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
 
     s16x8 qf[2][NKS], of[2][NKS];      // B operands of S^T = K Q^T and dP^T = V dO^T: lane holds row (32 qb + r), k = 16 ks + 8 h ..
     f32x16 dqa[2][NDB];
-    f32x16 sacc[2], pacc[2], ndt[2], mt[2];
+    f32x16 sacc[2][2], pacc[2], mt[2];   // sacc[pair][qb]: blocks alternate between the two pairs
     u32x4 dsb[2][2];
     s16x8 ring[RS];
-    float nl2[2];                       // -lse * log2(e) of this lane's two rows: P = exp2(c S + nl2)
+    float nl2[2], nd[2];                // this lane's two rows: -lse * log2(e) (P = exp2(c S + nl2)) and -delta
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     unsigned kaddr[NKS], tlo[NDB], thi[NDB];
     unsigned stamp_cycles = 0, stamp_tiles = 0;
@@ -143,12 +174,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
         static constexpr int reads(int g) { return (g % 24) < 16 ? 1 : 2; }
         static constexpr int slot(int g) { return (g % 24) % RS; }
     };
-    auto fetch = [&](auto gc, auto kbc) {   // prologue form (inside the stream the request rides in the MFMA's statement)
-        constexpr int g = decltype(gc)::value, kb = decltype(kbc)::value, ph = g / 8, i = g % 8;
-        static_assert(ph == 0, "only S^T groups are requested ahead of the stream");
-        ring[G::slot(g)] = lds_b128_asm<kb * 32 * 2 * D>(kaddr[i]);
-    };
-
     // The mask (diagonal blocks under the causal mask, keys past n) is the C operand of the first S^T MFMA: register i of
     // query block qb holds key k0 + 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2); it starts at -1e30 when that key lies past
     // the lane's row (or past n), so P = 0 and dS = 0.  Rebuilt between two blocks in a wave-uniform branch; all zeros
@@ -185,7 +210,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
 
     // ---- prologue of a query tile: Q, dO fragments; row constants (made here and stored for the dK/dV kernel:
     // -delta = -rowsum(dO * O), csrc/fa2/fa2_bwd.cu:57, from this lane's half of the row plus lane ^ 32's; -lse / scale)
-    float nd[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int row = q0w + 32 * qb + r;
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
             ndelta[(size_t)bh * n + row] = nd[qb];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ndt[qb][i] = nd[qb]; mt[qb][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) mt[qb][i] = 0.f;
 #pragma unroll
         for (int t = 0; t < NDB; ++t)
 #pragma unroll
@@ -244,111 +268,106 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
             asm volatile("" : "+a"(of[qb][ks]), "+a"(of[qb][ks + 1]), "+a"(of[qb][ks + 2]), "+a"(of[qb][ks + 3]));
         }
 
-    // ---- one 32-key block: 24 operand groups, two MFMAs each (query block 0, then 1)
-    //   g =  0 ..  7  S^T[qb]  += K[ks] Q[qb][ks]^T           request: K rows (one fragment)
-    //   g =  8 .. 15  dP^T[qb] += V[ks] dO[qb][ks]^T          request: V rows
-    //   g = 16 .. 23  dQ^T[qb][db] += K^T[s][db] dS^T[qb][s]  request: two transposed 4-row blocks of K
-    auto block = [&](auto kbc, int t) {   // t: key tile (relative to the query tile), kb: 32-key block in it
-        constexpr int KB = decltype(kbc)::value;
+    // ---- the stream, software-pipelined over 32-key blocks so that no chain is read right after it ends: iteration b
+    // runs 24 operand groups, two MFMAs each (query block 0, then 1):
+    //   g =  0 ..  7  dP^T[qb]     += V(b)[ks] dO[qb][ks]^T            request: V rows of block b
+    //   g =  8 .. 15  S^T(b+1)[qb] += K(b+1)[ks] Q[qb][ks]^T           request: K rows of block b + 1
+    //   g = 16 .. 23  dQ^T[qb][db] += K(b)^T[s][db] dS^T(b)[qb][s]     request: two transposed 4-row blocks of K
+    // and the vector work rides in their gaps: the second half of P^T(b) = exp2(c S^T(b) - lse) under the dP^T chains,
+    // dS^T(b) = P^T (dP^T - delta) under the S^T(b+1) chains (which use the other pair of S accumulators), the first half
+    // of P^T(b+1) under the dQ^T products.  One pair per gap at most: the matrix pipe sets the pace.
+    auto iter = [&](auto kbc, int t) {   // t: key tile (relative to the query tile), KB: 32-key block b in it
+        constexpr int KB = decltype(kbc)::value, CUR = KB, NXT = 1 - KB;   // S accumulator pairs of blocks b and b + 1
         const int dlt = ((gtile + t + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
         using std::integral_constant;
-        auto PE = [&](auto qbc, auto ic) {   // in place: sacc becomes P^T
-            constexpr int qb = decltype(qbc)::value, i = decltype(ic)::value;
-            sacc[qb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[qb][i], c_log2, nl2[qb]));
+        auto PE = [&](auto setc, auto qbc, auto ic) {   // in place: S^T becomes P^T
+            constexpr int st = decltype(setc)::value, qb = decltype(qbc)::value, i = decltype(ic)::value;
+            sacc[st][qb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[st][qb][i], c_log2, nl2[qb]));
         };
-        auto SU = [&](auto qbc, auto mc) {   // one packed dword of dS^T = P^T dP'^T
+        auto SU = [&](auto qbc, auto mc) {   // one packed dword of dS^T = P^T (dP^T - delta)
             constexpr int qb = decltype(qbc)::value, m = decltype(mc)::value;
-            dsb[qb][m >> 2][m & 3] = pack2<Tag>(sacc[qb][2 * m] * pacc[qb][2 * m], sacc[qb][2 * m + 1] * pacc[qb][2 * m + 1]);
+            dsb[qb][m >> 2][m & 3] = pack2<Tag>(sacc[CUR][qb][2 * m] * (pacc[qb][2 * m] + nd[qb]),
+                                                sacc[CUR][qb][2 * m + 1] * (pacc[qb][2 * m + 1] + nd[qb]));
         };
-        auto SU4 = [&](auto qbc, auto m0c) {
-            constexpr int m0 = decltype(m0c)::value;
-            SU(qbc, integral_constant<int, m0>{}); SU(qbc, integral_constant<int, m0 + 1>{});
-            SU(qbc, integral_constant<int, m0 + 2>{}); SU(qbc, integral_constant<int, m0 + 3>{});
-        };
-        // the vector work that follows MFMA S of the block (S = 0 .. 47).  S^T is complete after MFMA 15, dP^T after 31;
-        // P^T[.][s] dS feeds MFMAs 32 + 8 s ...; a consumer sits at least two MFMAs behind the chain it reads.
+        // the vector work that follows MFMA S of the iteration (S = 0 .. 47).  dP^T(b) is complete after MFMA 15,
+        // S^T(b+1) after MFMA 31; dS^T(b)[.][s] feeds MFMAs 32 + 8 s ...; a consumer sits at least two MFMAs behind the
+        // chain it reads (hipcc pads nothing around the asm MFMAs; tools/mfma_hazard_audit.py checks the distances).
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr ((ABL & 1) && S >= 17 && S <= 34) {}
-            else if constexpr (S >= 17 && S <= 30) {
-                // two exp2's per gap; query block 0 first (S = 17 .. 24), then 1; the last pairs go with the seam
-                constexpr int u = S - 17;
-                if constexpr (u < 14) {
-                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8)>{});
-                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8) + 1>{});
+            if constexpr (ABL & 1) {}
+            else if constexpr (S < 16) {
+                PE(integral_constant<int, CUR>{}, integral_constant<int, 1>{}, integral_constant<int, S>{});   // P^T(b), rows 32 ..
+                if constexpr (KB == 1 && (S == 8 || S == 9)) {   // V rows of this tile were last requested at MFMA 8
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) kaddr[4 * (S - 8) + j] += dlt;
                 }
-            } else if constexpr (S == 31) {
-                // the seam: dS needs dP'^T (last MFMAs 30 / 31).  The next tile's LDS-DMA pieces go here, then the
-                // rest of P^T and the first half of dS^T of query block 0.
-                if constexpr (!(ABL & 2)) {
-                    dma_piece(integral_constant<int, 4 * KB + 0>{}, t + 3);
-                    dma_piece(integral_constant<int, 4 * KB + 1>{}, t + 3);
-                    dma_piece(integral_constant<int, 4 * KB + 2>{}, t + 3);
-                    dma_piece(integral_constant<int, 4 * KB + 3>{}, t + 3);
+            } else if constexpr (S >= 17 && S <= 32) {
+                // pairs in the order the dQ^T products need them: (qb 0, s 0) x4, (qb 1, s 0) x4, (qb 0, s 1) x4, (qb 1, s 1) x4
+                constexpr int u = S - 17, qb = (u / 4) & 1, m = 4 * (u / 8) + (u % 4);
+                SU(integral_constant<int, qb>{}, integral_constant<int, m>{});
+                if constexpr (!(ABL & 2) && (S == 21 || S == 23 || S == 25 || S == 27))
+                    dma_piece(integral_constant<int, 4 * KB + (S - 21) / 2>{}, t + 3);
+                if constexpr (S == 32) PE(integral_constant<int, NXT>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            } else if constexpr (S >= 33 && S <= 47) {
+                PE(integral_constant<int, NXT>{}, integral_constant<int, 0>{}, integral_constant<int, S - 32>{});   // P^T(b+1), rows 0 ..
+                if constexpr (KB == 1 && S >= 41 && S <= 44) {   // last transposed request: MFMA 40
+                    tlo[S - 41] += dlt;
+                    thi[S - 41] += dlt;
                 }
-                PE(integral_constant<int, 1>{}, integral_constant<int, 12>{});
-                PE(integral_constant<int, 1>{}, integral_constant<int, 13>{});
-                PE(integral_constant<int, 1>{}, integral_constant<int, 14>{});
-                PE(integral_constant<int, 1>{}, integral_constant<int, 15>{});
-                SU4(integral_constant<int, 0>{}, integral_constant<int, 0>{});
-            } else if constexpr (S == 32) {
-                SU4(integral_constant<int, 1>{}, integral_constant<int, 0>{});
-                // the MFMA that follows reads dS^T[1][0] as its B operand: two wait states after the VALU write
-                asm volatile("s_nop 1" : "+v"(dsb[1][0]));
-            }
-            else if constexpr (S == 33) SU4(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-            else if constexpr (S == 34) SU4(integral_constant<int, 1>{}, integral_constant<int, 4>{});
-            else if constexpr (KB == 1 && S >= 36 && S <= 39) {     // K / V rows were last requested at MFMA 25
-                kaddr[2 * (S - 36)] += dlt;
-                kaddr[2 * (S - 36) + 1] += dlt;
-            } else if constexpr (KB == 1 && S >= 42 && S <= 45) {   // last transposed request: MFMA 41
-                tlo[S - 42] += dlt;
-                thi[S - 42] += dlt;
             }
         };
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value, ph = g / 8, i = g % 8, s0 = G::slot(g);
-            constexpr int NWAIT = G::reads(g + 1) + G::reads(g + 2) + G::reads(g + 3);
+            // one counted wait per TWO groups: an even group also waits for the next group's operands (requested a group
+            // later, so the lead is two groups for those), an odd group issues no wait at all — one instruction less per
+            // four MFMAs in a stream whose pace is set by the wave's instruction issue
+            constexpr bool WAITS = (g % 2) == 0;
+            constexpr int NWAIT = G::reads(g + 2) + G::reads(g + 3);
             constexpr int g2 = (g + AHEAD) % 24, ph2 = g2 / 8, i2 = g2 % 8, t0 = G::slot(g2);   // the group requested here
-            constexpr int kb2 = g + AHEAD >= 24 ? 1 - KB : KB;   // groups 24 .. 26 belong to the next block
+            // the 32-key block the requested group reads, as a row offset into the tile kaddr / tlo / thi point at:
+            // dP^T groups of this iteration and dQ^T groups: block b; S^T groups: block b + 1; dP^T groups of the
+            // NEXT iteration (g + 3 >= 24): block b + 1.  After the mid-iteration advance (KB == 1) kaddr already
+            // points at the next tile, whose block 0 is "b + 1".
+            constexpr bool next_blk = ph2 == 1 || g + AHEAD >= 24;
+            constexpr int kbr = next_blk ? (KB == 0 ? 1 : 0) : KB;
             const s16x8 opa = ring[s0];
-            // B operands, read where they are used: the slice between the two MFMAs may be what makes the second one
-            auto opb = [&](auto qbc) -> s16x8 {
+            auto opb = [&](auto qbc) -> s16x8 {   // read where it is used: a slice may be what makes the second one
                 constexpr int qb = decltype(qbc)::value;
-                if constexpr (ph == 0) return qf[qb][i];
-                else if constexpr (ph == 1) return of[qb][i];
+                if constexpr (ph == 0) return of[qb][i];
+                else if constexpr (ph == 1) return qf[qb][i];
                 else return *reinterpret_cast<s16x8*>(&dsb[qb][i / 4]);
             };
             const s16x8 opb0 = opb(integral_constant<int, 0>{});
             if constexpr (ABL & 4) {
-                if constexpr (ph == 0 && i == 0) M::first(opa, opb0, sacc[0], mt[0]);
-                else if constexpr (ph == 0) M::acc(opa, opb0, sacc[0]);
-                else if constexpr (ph == 1 && i == 0) M::first(opa, opb0, pacc[0], ndt[0]);
-                else if constexpr (ph == 1) M::acc(opa, opb0, pacc[0]);
+                if constexpr (ph == 0 && i == 0) M::first0(opa, opb0, pacc[0]);
+                else if constexpr (ph == 0) M::acc(opa, opb0, pacc[0]);
+                else if constexpr (ph == 1 && i == 0) M::first(opa, opb0, sacc[NXT][0], mt[0]);
+                else if constexpr (ph == 1) M::acc(opa, opb0, sacc[NXT][0]);
                 else M::acca(opa, opb0, dqa[0][i % 4]);
             } else if constexpr (ph2 < 2) {
-                // a row fragment: K rows of block kb2 (S^T) or V rows (dP^T) — of the NEXT tile's buffer when kb2 < KB
-                constexpr int off = kb2 * 32 * 2 * D + (ph2 == 1 ? KT : 0);
-                if constexpr (ph == 0 && i == 0) M::template r_first<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[0], mt[0]);
-                else if constexpr (ph == 0) M::template r_acc<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[0]);
-                else if constexpr (ph == 1 && i == 0) M::template r_first<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0], ndt[0]);
-                else if constexpr (ph == 1) M::template r_acc<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0]);
-                else M::template r_acca<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, dqa[0][i % 4]);
+                // a row fragment: V rows (dP^T, ph2 == 0) or K rows (S^T, ph2 == 1)
+                constexpr int off = kbr * 32 * 2 * D + (ph2 == 0 ? KT : 0);
+                if constexpr (ph == 0 && i == 0) { if constexpr (WAITS) M::template r_first0<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0]); else M::template r_first0_nw<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0]); }
+                else if constexpr (ph == 0) { if constexpr (WAITS) M::template r_acc<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0]); else M::template r_acc_nw<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, pacc[0]); }
+                else if constexpr (ph == 1 && i == 0) { if constexpr (WAITS) M::template r_first<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[NXT][0], mt[0]); else M::template r_first_nw<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[NXT][0], mt[0]); }
+                else if constexpr (ph == 1) { if constexpr (WAITS) M::template r_acc<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[NXT][0]); else M::template r_acc_nw<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, sacc[NXT][0]); }
+                else { if constexpr (WAITS) M::template r_acca<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, dqa[0][i % 4]); else M::template r_acca_nw<NWAIT, off>(kaddr[i2], ring[t0], opa, opb0, dqa[0][i % 4]); }
             } else {
-                constexpr int off = kb2 * 32 * 2 * D + (i2 / 4) * 16 * 2 * D;
+                constexpr int off = KB * 32 * 2 * D + (i2 / 4) * 16 * 2 * D;
                 s16x4 lo, hi;
-                if constexpr (ph == 1) M::template t_acc<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, pacc[0]);
-                else M::template t_acca<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, dqa[0][i % 4]);
+                static_assert(ph >= 1, "transposed blocks are requested from the S^T and dQ^T groups");
+                if constexpr (ph == 1) { if constexpr (WAITS) M::template t_acc<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, sacc[NXT][0]); else M::template t_acc_nw<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, sacc[NXT][0]); }
+                else { if constexpr (WAITS) M::template t_acca<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, dqa[0][i % 4]); else M::template t_acca_nw<NWAIT, off>(tlo[i2 % 4], thi[i2 % 4], lo, hi, opa, opb0, dqa[0][i % 4]); }
                 ring[t0] = cat8(lo, hi);
             }
             __builtin_amdgcn_sched_barrier(0);
             slice(integral_constant<int, 2 * g>{});
             __builtin_amdgcn_sched_barrier(0);
             const s16x8 opb1 = opb(integral_constant<int, 1>{});
-            if constexpr (ph == 0 && i == 0) M::first(opa, opb1, sacc[1], mt[1]);
-            else if constexpr (ph == 0) M::acc(opa, opb1, sacc[1]);
-            else if constexpr (ph == 1 && i == 0) M::first(opa, opb1, pacc[1], ndt[1]);
-            else if constexpr (ph == 1) M::acc(opa, opb1, pacc[1]);
+            if constexpr (ph == 0 && i == 0) M::first0(opa, opb1, pacc[1]);
+            else if constexpr (ph == 0) M::acc(opa, opb1, pacc[1]);
+            else if constexpr (ph == 1 && i == 0) M::first(opa, opb1, sacc[NXT][1], mt[1]);
+            else if constexpr (ph == 1) M::acc(opa, opb1, sacc[NXT][1]);
             else M::acca(opa, opb1, dqa[1][i % 4]);
             __builtin_amdgcn_sched_barrier(0);
             slice(integral_constant<int, 2 * g + 1>{});
@@ -358,20 +377,37 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
     };
 
     if (ntiles_w > 0) {
+        // ---- lead-in: S^T(0) chains (block 0 of tile 0) and the first half of P^T(0); V rows of block 0 in flight
+        using std::integral_constant;
+        mask_setup(q0w, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts are exact
-        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        fetch(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        fetch(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        for_each_const([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            s16x8 kr = lds_b128_asm<0>(kaddr[ks]);
+            lds_wait_for<0>(kr);
+            if constexpr (ks == 0) { M::first(kr, qf[0][0], sacc[0][0], mt[0]); M::first(kr, qf[1][0], sacc[0][1], mt[1]); }
+            else { M::acc(kr, qf[0][ks], sacc[0][0]); M::acc(kr, qf[1][ks], sacc[0][1]); }
+        }, std::make_integer_sequence<int, NKS>{});
+        // the requests of the first three dP^T groups ride here; they also put 3 + MFMAs' worth of distance behind the chains
+        for_each_const([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            ring[G::slot(g)] = lds_b128_asm<KT>(kaddr[g]);
+        }, std::make_integer_sequence<int, AHEAD>{});
+        asm volatile("s_nop 15" : "+v"(sacc[0][0]), "+v"(sacc[0][1]));
+        if (!(ABL & 1)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[0][0][i] = __builtin_amdgcn_exp2f(fmaf(sacc[0][0][i], c_log2, nl2[0]));
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     unsigned long long t_begin = 0;
     if (ABL & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
 #pragma unroll 1
     for (int t = 0; t < ntiles_w; ++t) {
-        mask_setup(q0w, BN * t);
-        block(std::integral_constant<int, 0>{}, t);
-        mask_setup(q0w, BN * t + 32);
-        block(std::integral_constant<int, 1>{}, t);
+        mask_setup(q0w, BN * t + 32);          // of the block whose S^T chains run in the coming iteration: b + 1
+        iter(std::integral_constant<int, 0>{}, t);
+        mask_setup(q0w, BN * t + 64);
+        iter(std::integral_constant<int, 1>{}, t);
         if (!(ABL & 2)) {
             wait_tiles();
             __builtin_amdgcn_s_barrier();
