@@ -30,7 +30,7 @@ std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_free;
 hipEvent_t g_prof_open[fa::K_COUNT];
 const char* const kKernelNames[fa::K_COUNT] = {"fwd_f32", "bwd_delta", "bwd_dkdv_f32", "bwd_dq_f32", "fwd_mfma",
-                                               "bwd_mfma", "bwd_dq_cvt", "bwd_dq_mfma", "fp8_quant", "fwd_fp8"};
+                                               "bwd_mfma", "bwd_dq_cvt", "bwd_dq_mfma", "fp8_quant", "fwd_fp8", "ex_fwd", "ex_bwd"};
 
 hipEvent_t prof_get_event() {
     if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
@@ -300,6 +300,62 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
     }
     return backward_impl("fa3_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
                          workspace, workspace_bytes, stream);
+}
+
+// ---- extended attention: see include/fa_mi355x.h
+static int ex_check(const char* who, int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype, double scale, const uint8_t* block_mask,
+                    int64_t br, int64_t bc, double p) {
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_F16 && dtype != FA_DTYPE_BF16)
+        return fail(FA_ERR_INVALID_ARGUMENT, "%s: unknown dtype code %d", who, dtype);
+    if (bh < 0 || nq < 0 || nk < 0 || d <= 0)
+        return fail(FA_ERR_INVALID_ARGUMENT, "%s: bad shape (BH=%lld, Nq=%lld, Nk=%lld, d=%lld)", who, (long long)bh, (long long)nq,
+                    (long long)nk, (long long)d);
+    if (d > 256) return fail(FA_ERR_UNSUPPORTED, "%s: head_dim %lld > 256 is not supported", who, (long long)d);
+    if (nq > (int64_t)1 << 24 || nk > (int64_t)1 << 24 || nq * d >= ((int64_t)1 << 31) || nk * d >= ((int64_t)1 << 31) ||
+        bh * ((nq + 15) / 16) >= ((int64_t)1 << 31) || bh * ((nk + 15) / 16) >= ((int64_t)1 << 31))
+        return fail(FA_ERR_UNSUPPORTED, "%s: problem too large for one launch", who);
+    if (!(scale == scale)) return fail(FA_ERR_INVALID_ARGUMENT, "%s: softmax_scale is NaN", who);
+    if (block_mask && (br <= 0 || bc <= 0)) return fail(FA_ERR_INVALID_ARGUMENT, "%s: block-sparse mask needs br, bc > 0", who);
+    if (!(p >= 0.0 && p < 1.0)) return fail(FA_ERR_INVALID_ARGUMENT, "%s: dropout_p must lie in [0, 1)", who);
+    return FA_OK;
+}
+
+int fa_ex_forward(const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh, int64_t nq, int64_t nk, int64_t d,
+                  int dtype, int causal, double softmax_scale, const uint8_t* mask, int64_t mask_bh_stride,
+                  const uint8_t* block_mask, int64_t br, int64_t bc, double dropout_p, uint64_t dropout_seed, void* stream) {
+    int rc = ex_check("fa_ex_forward", bh, nq, nk, d, dtype, softmax_scale, block_mask, br, bc, dropout_p);
+    if (rc != FA_OK) return rc;
+    if (bh == 0 || nq == 0) return FA_OK;
+    if (!q || !o || !lse || (nk > 0 && (!k || !v))) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_forward: null tensor pointer");
+    fa::ExArgs a{q, k, v, o, lse, nullptr, nullptr, nullptr, nullptr, bh, nq, nk, d, dtype, causal ? 1 : 0, (float)softmax_scale,
+                 mask, mask_bh_stride, block_mask, br, bc, dropout_p, dropout_seed, nullptr};
+    hipError_t e = fa::launch_ex(a, false, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_ex_forward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+    return FA_OK;
+}
+
+int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse, void* dq, void* dk,
+                   void* dv, int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype, int causal, double softmax_scale,
+                   const uint8_t* mask, int64_t mask_bh_stride, const uint8_t* block_mask, int64_t br, int64_t bc, double dropout_p,
+                   uint64_t dropout_seed, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = ex_check("fa_ex_backward", bh, nq, nk, d, dtype, softmax_scale, block_mask, br, bc, dropout_p);
+    if (rc != FA_OK) return rc;
+    if (bh == 0 || (nq == 0 && nk == 0)) return FA_OK;
+    if (!q || !k || !v || !o || !do_ || !lse || !dq || !dk || !dv) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_backward: null tensor pointer");
+    const size_t need = fa_ex_backward_workspace_bytes(bh, nq, nk, d, dtype);
+    if (!workspace || workspace_bytes < need)
+        return fail(FA_ERR_WORKSPACE, "fa_ex_backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    fa::ExArgs a{q, k, v, const_cast<void*>(o), const_cast<float*>(lse), do_, dq, dk, dv, bh, nq, nk, d, dtype, causal ? 1 : 0,
+                 (float)softmax_scale, mask, mask_bh_stride, block_mask, br, bc, dropout_p, dropout_seed, workspace};
+    hipError_t e = fa::launch_ex(a, true, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_ex_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+    return FA_OK;
+}
+
+size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype) {
+    (void)nk; (void)d; (void)dtype;
+    if (bh <= 0 || nq <= 0) return 256;
+    return (fa::ex_backward_workspace_bytes(bh, nq) + 255) & ~(size_t)255;
 }
 
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {

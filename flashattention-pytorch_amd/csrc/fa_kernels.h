@@ -32,7 +32,7 @@ struct BwdArgs {
 // Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
 // roofline figure; off by default, costs nothing when off).
 enum KernelId { K_FWD_F32 = 0, K_BWD_DELTA, K_BWD_DKDV_F32, K_BWD_DQ_F32, K_FWD_MFMA, K_BWD_MFMA, K_BWD_DQ_CVT, K_BWD_DQ_MFMA,
-                K_FP8_QUANT, K_FWD_FP8, K_COUNT };
+                K_FP8_QUANT, K_FWD_FP8, K_EX_FWD, K_EX_BWD, K_COUNT };
 void prof_begin(int id, hipStream_t st);
 void prof_end(int id, hipStream_t st);
 struct ProfScope {
@@ -81,5 +81,27 @@ hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st);
 size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
 hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
                                 hipStream_t st);
+
+// Extended attention (fa_ex.hip): Nq != Nk with a bottom-right aligned causal mask, dense mask, block-sparse mask,
+// dropout.  Exact-f32 kernels, any dtype, d <= 256.
+struct ExArgs {
+    const void *q, *k, *v;        // q: (bh, nq, d); k, v: (bh, nk, d)
+    void* o;                      // (bh, nq, d)
+    float* lse;                   // (bh, nq)
+    const void* dout;             // backward: (bh, nq, d)
+    void *dq, *dk, *dv;           // backward outputs
+    int64_t bh, nq, nk, d;
+    int dtype, causal;
+    float scale;
+    const uint8_t* mask;          // (nq, nk) bytes, 0 = masked; null = none
+    int64_t mask_bh_stride;       // 0 = one mask shared by all (b,h), nq * nk = one per (b,h)
+    const uint8_t* block_mask;    // (ceil(nq/br), ceil(nk/bc)) bytes, 0 = tile skipped; null = none
+    int64_t br, bc;
+    double dropout_p;
+    uint64_t seed;
+    void* workspace;              // backward: ex_backward_workspace_bytes
+};
+hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st);
+size_t ex_backward_workspace_bytes(int64_t bh, int64_t nq);
 
 }  // namespace fa

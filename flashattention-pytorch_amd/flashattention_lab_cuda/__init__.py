@@ -32,6 +32,7 @@ EXPORTED_C_SYMBOLS = (
     "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
     "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
     "fa_set_kernel_mode", "fa_set_option", "fa_debug_trace_buffer", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
+    "fa_ex_forward", "fa_ex_backward", "fa_ex_backward_workspace_bytes",
 )
 
 
@@ -75,6 +76,14 @@ def _load_library() -> ctypes.CDLL:
     lib.fa_profile_enable.restype = ci
     lib.fa_profile_report.argtypes = [ctypes.c_char_p, sz]
     lib.fa_profile_report.restype = ci
+    u64 = ctypes.c_uint64
+    lib.fa_ex_forward.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, dbl, vp, i64, vp, i64, i64, dbl, u64, vp]
+    lib.fa_ex_forward.restype = ci
+    lib.fa_ex_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, dbl, vp, i64, vp, i64, i64, dbl, u64,
+                                   vp, sz, vp]
+    lib.fa_ex_backward.restype = ci
+    lib.fa_ex_backward_workspace_bytes.argtypes = [i64, i64, i64, i64, ci]
+    lib.fa_ex_backward_workspace_bytes.restype = sz
     return lib
 
 
@@ -213,3 +222,65 @@ def fa3_forward(q, k, v, causal, softmax_scale, br, bc, stages, fp8):
 def fa3_backward(q, k, v, o, do_, lse, causal, softmax_scale, br, bc, stages, fp8):
     return _backward(_lib.fa3_backward, "fa3_backward", q, k, v, o, do_, lse, causal, softmax_scale, br, bc,
                      extra=(stages, fp8))
+
+
+# ---- extended attention (include/fa_mi355x.h: fa_ex_forward / fa_ex_backward) ----
+
+def _ex_common(who, q, k, v, mask, block_mask, br, bc):
+    for t in (q, k, v):
+        if not t.is_cuda:
+            raise RuntimeError(f"{who}: tensors must be on the GPU (HIP device); there is no CPU path")
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
+        raise RuntimeError(f"{who}: q must be (BH, Nq, d), k and v (BH, Nk, d); got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if q.dtype not in _DTYPE_CODE or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError(f"{who}: q, k, v must share a supported dtype")
+    bh, nq, d = q.shape
+    nk = k.shape[1]
+    mptr, mstride = 0, 0
+    if mask is not None:
+        mask = mask.to(device=q.device, dtype=torch.uint8).contiguous()   # 0 = masked
+        if tuple(mask.shape) == (nq, nk):
+            mstride = 0
+        elif tuple(mask.shape) == (bh, nq, nk):
+            mstride = nq * nk
+        else:
+            raise RuntimeError(f"{who}: mask must be (Nq, Nk) or (BH, Nq, Nk), got {tuple(mask.shape)}")
+        mptr = mask.data_ptr()
+    bptr = 0
+    if block_mask is not None:
+        block_mask = block_mask.to(device=q.device, dtype=torch.uint8).contiguous()
+        want = ((nq + br - 1) // br, (nk + bc - 1) // bc)
+        if tuple(block_mask.shape) != want:
+            raise RuntimeError(f"{who}: block_sparse_mask must be {want} for br={br}, bc={bc}, got {tuple(block_mask.shape)}")
+        bptr = block_mask.data_ptr()
+    return bh, nq, nk, d, _DTYPE_CODE[q.dtype], mask, mptr, mstride, block_mask, bptr
+
+
+def ex_forward(q, k, v, causal, softmax_scale, mask=None, block_mask=None, br=128, bc=128, dropout_p=0.0, seed=0):
+    """(o, lse) of attention with Nq != Nk (causal aligned bottom-right), dense mask (0 = masked), block-sparse mask
+    (0 = tile skipped) and dropout; see include/fa_mi355x.h."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    bh, nq, nk, d, code, mask, mptr, mstride, block_mask, bptr = _ex_common("ex_forward", q, k, v, mask, block_mask, br, bc)
+    with torch.cuda.device(q.device):
+        o = torch.empty_like(q)
+        lse = torch.empty((bh, nq), dtype=torch.float32, device=q.device)
+        _check(_lib.fa_ex_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), bh, nq, nk, d, code,
+                                  int(bool(causal)), float(softmax_scale), mptr, mstride, bptr, int(br), int(bc), float(dropout_p),
+                                  int(seed) & (2 ** 64 - 1), _stream_ptr(q.device)))
+    return o, lse
+
+
+def ex_backward(q, k, v, o, do_, lse, causal, softmax_scale, mask=None, block_mask=None, br=128, bc=128, dropout_p=0.0, seed=0):
+    q, k, v, o, do_, lse = (t.contiguous() for t in (q, k, v, o, do_, lse))
+    bh, nq, nk, d, code, mask, mptr, mstride, block_mask, bptr = _ex_common("ex_backward", q, k, v, mask, block_mask, br, bc)
+    if o.shape != q.shape or do_.shape != q.shape or lse.shape != (bh, nq) or lse.dtype != torch.float32:
+        raise RuntimeError("ex_backward: o, do must be (BH, Nq, d) and lse (BH, Nq) float32")
+    with torch.cuda.device(q.device):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nbytes = int(_lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, code))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        _check(_lib.fa_ex_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
+                                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, nq, nk, d, code, int(bool(causal)),
+                                   float(softmax_scale), mptr, mstride, bptr, int(br), int(bc), float(dropout_p),
+                                   int(seed) & (2 ** 64 - 1), ws.data_ptr(), nbytes, _stream_ptr(q.device)))
+    return dq, dk, dv

@@ -97,6 +97,37 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
                  int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* --- Extended attention: the extras the reference's notebook model wires around its tiled attention,
+ * src/fa3/torch/flashattention_pytorch.py (MultiHeadAttention._block_sparse_flash_attention :94-174, look_ahead_mask_ :176-190,
+ * dense branch :80-87; src/common/dropout.py:3-15), as kernel features behind one entry point.
+ *   q, o, do, dq : (BH, Nq, d)      k, v, dk, dv : (BH, Nk, d)      lse : (BH, Nq) float32
+ *   causal != 0      : key j is visible to query i iff j <= i + (Nk - Nq)          (look_ahead_mask_, bottom-right aligned)
+ *   mask             : Nq x Nk bytes, 0 = masked (masked_fill(mask == 0, -inf)); mask_bh_stride = 0 shares one mask over all
+ *                      (b,h), Nq*Nk gives every (b,h) its own; NULL = none
+ *   block_mask       : ceil(Nq/br) x ceil(Nk/bc) bytes, 0 = the tile is skipped (Algorithm 5 line 8); NULL = none
+ *   dropout_p, seed  : standard dropout of the attention probabilities, keep where u > p, scale 1/(1-p); u comes from a
+ *                      counter-based generator of (seed, b*h, i, j), so the backward regenerates the same mask; 0 = none
+ *   softmax_scale    : includes the model's temperature tau
+ * A query row with no visible key returns o = 0, lse = -inf (the reference's softmax of an all -inf row is NaN).
+ * Exact-f32 kernels (every dtype, d <= 256). */
+int fa_ex_forward(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype,
+                  int causal, double softmax_scale,
+                  const uint8_t* mask, int64_t mask_bh_stride,
+                  const uint8_t* block_mask, int64_t br, int64_t bc,
+                  double dropout_p, uint64_t dropout_seed, void* stream);
+
+int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                   void* dq, void* dk, void* dv,
+                   int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype,
+                   int causal, double softmax_scale,
+                   const uint8_t* mask, int64_t mask_bh_stride,
+                   const uint8_t* block_mask, int64_t br, int64_t bc,
+                   double dropout_p, uint64_t dropout_seed,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype);
+
 /* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */
 /* bytes for the CURRENT kernel mode: two float row constants per query row (+ an fp32 dQ scratch of bh*n*d floats in
  * FA_MODE_BWD_ATOMIC only); ask again after changing the mode */

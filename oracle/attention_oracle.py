@@ -307,3 +307,75 @@ def attention_flops(bh: int, n: int, d: int, direction: str, causal: bool = Fals
     if causal:
         f *= (n + 1) / (2.0 * n)
     return f
+
+
+# ---- extended attention: Nq != Nk causal offset, dense mask, block-sparse mask, dropout ----
+# Restates the attention core of the reference's notebook model: scores = tau * q k^T / sqrt(d), masked_fill(mask == 0,
+# -inf) (src/fa3/torch/flashattention_pytorch.py:134-141, 80-84), look_ahead_mask_ (:176-190), tiles with
+# block_sparse_mask[i, j] == 0 skipped (:123-125), dropout of the probabilities: keep where rnd > p, scale 1 / (1 - p)
+# (src/common/dropout.py:9-15, flashattention_pytorch.py:85-87 — the dense branch's standard dropout, O = dropout(softmax) V;
+# the tiled branch's renormalisation by the kept sum, :155-163, is a defect and is not reproduced).
+
+def dropout_keep(bh, nq, nk, p, seed):
+    """(bh, nq, nk) boolean keep mask of the HIP kernels' counter-based generator (csrc/fa_ex.hip: ex_keep): splitmix64 of
+    (seed, element index), the top 24 bits as a uniform in [0, 1), keep iff u > p.  numpy uint64 arithmetic wraps like the
+    device's."""
+    import numpy as np
+
+    if p <= 0.0:
+        return torch.ones((bh, nq, nk), dtype=torch.bool)
+    with np.errstate(over="ignore"):
+        idx = np.arange(bh * nq * nk, dtype=np.uint64)
+        g = np.uint64(0x9E3779B97F4A7C15)
+        z = idx + np.uint64(seed % (1 << 64)) * g + g
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy((u > np.float32(p)).reshape(bh, nq, nk))
+
+
+def extended_visible(bh, nq, nk, causal=False, mask=None, block_mask=None, br=128, bc=128):
+    """(bh, nq, nk) boolean: which (query, key) pairs take part."""
+    vis = torch.ones((bh, nq, nk), dtype=torch.bool)
+    if causal:
+        qi = torch.arange(nq).unsqueeze(1)
+        kj = torch.arange(nk).unsqueeze(0)
+        vis &= (kj <= qi + (nk - nq)).unsqueeze(0)
+    if mask is not None:
+        m = (mask != 0)
+        vis &= m.unsqueeze(0) if m.dim() == 2 else m
+    if block_mask is not None:
+        bm = (block_mask != 0)
+        full = bm.repeat_interleave(br, dim=0)[:nq].repeat_interleave(bc, dim=1)[:, :nk]
+        vis &= full.unsqueeze(0)
+    return vis
+
+
+def extended_attention(q, k, v, causal=False, softmax_scale=None, mask=None, block_mask=None, br=128, bc=128, dropout_p=0.0,
+                       seed=0, math_dtype=torch.float64):
+    """(o, lse) in `math_dtype`; rows without a visible key: o = 0, lse = -inf (the kernels' convention)."""
+    bh, nq, d = q.shape
+    nk = k.shape[1]
+    scale = d ** -0.5 if softmax_scale is None else softmax_scale
+    qf, kf, vf = q.to(math_dtype), k.to(math_dtype), v.to(math_dtype)
+    s = qf @ kf.transpose(1, 2) * scale
+    vis = extended_visible(bh, nq, nk, causal, mask, block_mask, br, bc)
+    s = s.masked_fill(~vis, float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    dead = ~vis.any(dim=-1)
+    p = torch.exp(s - lse.masked_fill(dead, 0.0).unsqueeze(-1))
+    p = p.masked_fill(~vis, 0.0)
+    if dropout_p > 0.0:
+        p = p * dropout_keep(bh, nq, nk, dropout_p, seed).to(math_dtype) / (1.0 - dropout_p)
+    o = p @ vf
+    return o, lse
+
+
+def extended_attention_backward(q, k, v, do, **kw):
+    """(dq, dk, dv, o, lse) by autograd through extended_attention (fp64), results cast to q.dtype except lse."""
+    math_dtype = kw.get("math_dtype", torch.float64)
+    qf, kf, vf = (t.detach().to(math_dtype).requires_grad_(True) for t in (q, k, v))
+    o, lse = extended_attention(qf, kf, vf, **kw)
+    (o * do.to(math_dtype)).sum().backward()
+    return qf.grad.to(q.dtype), kf.grad.to(q.dtype), vf.grad.to(q.dtype), o.detach().to(q.dtype), lse.detach().float()

@@ -11,7 +11,21 @@ DT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 
 def golden_tags(pattern="*"):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, pattern + ".npz")))
+    """the hot path's fixtures (tests/golden/make_golden.py); the extended-attention ones are listed by ex_golden_tags()"""
+    tags = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, pattern + ".npz")))
+    return [t for t in tags if not t.startswith("ex_")] if pattern == "*" else tags
+
+
+def ex_golden_tags():
+    return golden_tags("ex_*")
+
+
+def load_ex_golden(tag):
+    """(meta, tensors) of an extended-attention fixture (tests/golden/make_golden_ex.py): q (B,H,Nq,d), k, v (B,H,Nk,d),
+    o (B,H,Nq,d) fp32; block_mask uint8; mask uint8 (Nq, Nk) when present."""
+    z = np.load(os.path.join(GOLDEN_DIR, tag + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, {k: torch.from_numpy(z[k].copy()) for k in z.files if k != "meta"}
 
 
 def load_golden(tag):

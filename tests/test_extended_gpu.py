@@ -1,0 +1,136 @@
+"""GPU parity of the extended attention path through the C-ABI (`fa_ex_forward` / `fa_ex_backward`):
+against the golden vectors of the reference's notebook code, and against the fp64 oracle — forward and backward — for
+Nq != Nk with the bottom-right causal mask, dense masks (shared and per (b,h)), block-sparse masks, dropout (the kernels'
+counter-based mask is reproduced bit for bit by the oracle, so dropout is an exact-parity case, not a statistical one) and
+all of them together; ragged sizes, head dims 40 / 64 / 128, three dtypes, rows without any visible key."""
+import pytest
+import torch
+
+from oracle import attention_oracle as orc
+from tests.helpers import dtype_tolerances, ex_golden_tags, load_ex_golden, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ex_golden_tags())
+def test_hip_matches_reference_notebook_vectors(tag, device):
+    from common.attention_ex import flash_attention_ex
+
+    meta, g = load_ex_golden(tag)
+    q, k, v = (g[x].to(device) for x in "qkv")              # (B, H, N, d), as the model passes them
+    mask = g["mask"].to(device) if "mask" in g else None
+    o = flash_attention_ex(q, k, v, tau=meta["tau"], mask=mask, block_sparse_mask=g["block_mask"].to(device),
+                           block_size=meta["block_size"])
+    assert o.shape == q.shape
+    assert max_abs(o.cpu(), g["o"]) < 1e-4                   # fp32 bar of the reference's tests (tests/utils.py:36)
+    if meta["causal"] and not meta["dense_mask"]:            # the same mask, not materialised
+        o2 = flash_attention_ex(q, k, v, tau=meta["tau"], causal=True, block_sparse_mask=g["block_mask"].to(device),
+                                block_size=meta["block_size"])
+        assert max_abs(o2.cpu(), g["o"]) < 1e-4
+
+
+def _case(bh, nq, nk, d, dtype, seed, mask_kind=None, block=None, density=0.6):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn((bh, nq, d), generator=g).to(dtype)
+    k = torch.randn((bh, nk, d), generator=g).to(dtype)
+    v = torch.randn((bh, nk, d), generator=g).to(dtype)
+    do = torch.randn((bh, nq, d), generator=g).to(dtype)
+    mask = bmask = None
+    if mask_kind == "shared":
+        mask = (torch.rand((nq, nk), generator=g) < density).to(torch.uint8)
+    elif mask_kind == "per_bh":
+        mask = (torch.rand((bh, nq, nk), generator=g) < density).to(torch.uint8)
+    if block is not None:
+        br, bc = block
+        bmask = (torch.rand(((nq + br - 1) // br, (nk + bc - 1) // bc), generator=g) < density).to(torch.uint8)
+    return q, k, v, do, mask, bmask
+
+
+CASES = [
+    # bh, nq, nk, d, causal, mask_kind, block (br, bc), dropout_p
+    (2, 40, 72, 32, True, None, None, 0.0),          # keys longer than queries: cached past keys
+    (2, 100, 37, 64, True, None, None, 0.0),         # queries longer than keys: the first rows see nothing
+    (3, 65, 130, 40, False, "shared", None, 0.0),
+    (2, 70, 70, 64, False, "per_bh", None, 0.0),
+    (2, 200, 300, 64, False, None, (32, 64), 0.0),
+    (1, 257, 257, 128, True, None, (64, 64), 0.0),
+    (2, 90, 120, 64, False, None, None, 0.3),
+    (2, 128, 128, 128, True, None, None, 0.1),
+    (2, 150, 210, 48, True, "shared", (32, 32), 0.25),   # everything at once
+    (1, 1, 5, 16, False, None, None, 0.0),
+    (1, 33, 1, 8, True, None, None, 0.0),
+]
+
+
+@pytest.mark.parametrize("bh,nq,nk,d,causal,mask_kind,block,p", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_forward_and_backward_match_the_oracle(bh, nq, nk, d, causal, mask_kind, block, p, dtype, device):
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do, mask, bmask = _case(bh, nq, nk, d, dtype, seed=1000 + nq + nk + d, mask_kind=mask_kind, block=block)
+    br, bc = block if block is not None else (128, 128)
+    scale, seed = 0.9 * d ** -0.5, 4242 + nq
+    kw = dict(causal=causal, softmax_scale=scale, mask=mask, block_mask=bmask, br=br, bc=bc, dropout_p=p, seed=seed)
+    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q, k, v, do, **kw)
+    dev = lambda t: None if t is None else t.to(device)
+    o, lse = ext.ex_forward(dev(q), dev(k), dev(v), causal, scale, dev(mask), dev(bmask), br, bc, p, seed)
+    dq, dk, dv = ext.ex_backward(dev(q), dev(k), dev(v), o, dev(do), lse, causal, scale, dev(mask), dev(bmask), br, bc, p, seed)
+    tol = dtype_tolerances(dtype)
+    torch.testing.assert_close(o.cpu(), ro, **tol)
+    live = torch.isfinite(rlse)
+    assert torch.equal(torch.isfinite(lse.cpu()), live)          # rows without a visible key: lse = -inf, exactly those
+    torch.testing.assert_close(lse.cpu()[live], rlse[live], rtol=1e-3, atol=1e-3)
+    assert torch.equal(o.cpu()[~live], torch.zeros_like(o.cpu()[~live]))
+    for name, a, b in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert torch.isfinite(a.float()).all(), name
+        torch.testing.assert_close(a.cpu(), b, **tol)
+    if dtype == torch.float32:
+        assert max_abs(o.cpu(), ro) < 5e-5 and max(max_abs(dq.cpu(), rq), max_abs(dk.cpu(), rk), max_abs(dv.cpu(), rv)) < 2e-4
+
+
+def test_extras_off_is_the_plain_path_and_dropout_is_reproducible(device):
+    """No extras: the extended entry point computes what the plain one does.  Dropout: the same seed gives the same result
+    bit for bit (forward and backward), another seed another mask, and E[o] over seeds approaches the undropped o."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do, _, _ = _case(3, 96, 96, 64, torch.float32, seed=5)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    o, lse = ext.ex_forward(qd, kd, vd, True, 0.125)
+    o0, lse0 = ext.forward(qd, kd, vd, True, 0.125, 128, 128)
+    assert max_abs(o, o0) < 2e-5 and max_abs(lse, lse0) < 2e-5
+    a = ext.ex_forward(qd, kd, vd, False, 0.125, dropout_p=0.5, seed=11)
+    b = ext.ex_forward(qd, kd, vd, False, 0.125, dropout_p=0.5, seed=11)
+    c = ext.ex_forward(qd, kd, vd, False, 0.125, dropout_p=0.5, seed=12)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], c[0])
+    assert torch.equal(a[1], c[1])                                # lse does not see the dropout
+    ga = ext.ex_backward(qd, kd, vd, a[0], dod, a[1], False, 0.125, dropout_p=0.5, seed=11)
+    gb = ext.ex_backward(qd, kd, vd, b[0], dod, b[1], False, 0.125, dropout_p=0.5, seed=11)
+    assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+    plain = ext.ex_forward(qd, kd, vd, False, 0.125)[0]
+    mean = sum(ext.ex_forward(qd, kd, vd, False, 0.125, dropout_p=0.3, seed=s)[0] for s in range(200)) / 200
+    assert max_abs(mean, plain) < 0.2
+
+
+def test_autograd_wrapper_and_error_behaviour(device):
+    from common.attention_ex import flash_attention_ex, look_ahead_mask
+
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn((2, 3, 20, 32), generator=g).to(device).requires_grad_(True)
+    k = torch.randn((2, 3, 50, 32), generator=g).to(device).requires_grad_(True)
+    v = torch.randn((2, 3, 50, 32), generator=g).to(device).requires_grad_(True)
+    o = flash_attention_ex(q, k, v, mask=look_ahead_mask(20, 50, device=device))
+    o2 = flash_attention_ex(q, k, v, causal=True)
+    assert o.shape == q.shape and torch.equal(o, o2)
+    o.sum().backward()
+    ro, _ = orc.extended_attention(q.detach().cpu().reshape(6, 20, 32), k.detach().cpu().reshape(6, 50, 32),
+                                   v.detach().cpu().reshape(6, 50, 32), causal=True)
+    assert max_abs(o.detach().cpu().reshape(6, 20, 32), ro) < 1e-4
+    assert q.grad is not None and torch.isfinite(q.grad).all() and torch.isfinite(k.grad).all()
+    import flashattention_lab_cuda as ext
+    with pytest.raises(RuntimeError):   # k and v must agree, q and k must share BH and d
+        ext.ex_forward(q.detach().reshape(6, 20, 32), k.detach().reshape(6, 50, 32), v.detach().reshape(6, 50, 32)[:, :40], False, 0.1)
+    with pytest.raises(RuntimeError, match="mask"):
+        ext.ex_forward(q.detach().reshape(6, 20, 32), k.detach().reshape(6, 50, 32), v.detach().reshape(6, 50, 32), False, 0.1,
+                       mask=torch.ones(20, 49, dtype=torch.uint8, device=device))
+    with pytest.raises(RuntimeError, match="dropout_p"):
+        ext.ex_forward(q.detach().reshape(6, 20, 32), k.detach().reshape(6, 50, 32), v.detach().reshape(6, 50, 32), False, 0.1, dropout_p=1.0)
