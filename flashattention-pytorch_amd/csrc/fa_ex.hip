@@ -15,52 +15,12 @@
 // dense branch (:85-87); its tiled branch renormalises by the sum of the KEPT probabilities (:155-163), which is a
 // different function and is not reproduced.
 #include "fa_common.h"
+#include "fa_ex_common.h"
 #include "fa_kernels.h"
 
 namespace fa {
 
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-struct ExParams {
-    int nq, nk, d;
-    int causal;            // 0 | 1 (bottom-right aligned)
-    int coff;              // nk - nq
-    const uint8_t* mask;   // [nq][nk] bytes or null
-    long long mask_bh;     // elements between the masks of consecutive (b,h): 0 = shared
-    const uint8_t* bmask;  // [nbr][nbc] bytes or null
-    int br, bc, nbc;
-    float p_drop, keep_scale;   // keep_scale = 1 / (1 - p)
-    unsigned long long seed;
-    float scale;
-};
-
-// splitmix64 of (seed, element index): 24 uniform bits.  The oracle (oracle/attention_oracle.py: dropout_keep) runs the
-// same arithmetic on uint64, so the masks agree bit for bit.
-__device__ __forceinline__ bool ex_keep(const ExParams& p, int bh, int row, int key) {
-    if (p.p_drop <= 0.f) return true;
-    unsigned long long z = ((unsigned long long)bh * (unsigned)p.nq + (unsigned)row) * (unsigned)p.nk + (unsigned)key;
-    z += p.seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);   // [0, 1)
-    return u > p.p_drop;
-}
-__device__ __forceinline__ bool ex_visible(const ExParams& p, int bh, int row, int key) {
-    if (row >= p.nq || key >= p.nk) return false;
-    if (p.causal && key > row + p.coff) return false;
-    if (p.mask && p.mask[(size_t)bh * p.mask_bh + (size_t)row * p.nk + key] == 0) return false;
-    if (p.bmask && p.bmask[(row / p.br) * p.nbc + key / p.bc] == 0) return false;
-    return true;
-}
-// does the block-sparse mask leave anything of rows [r0, r1) x keys [k0, k1)?  (uniform over the workgroup)
-__device__ __forceinline__ bool ex_tile_live(const ExParams& p, int r0, int r1, int k0, int k1) {
-    if (!p.bmask) return true;
-    for (int rb = r0 / p.br; rb <= (r1 - 1) / p.br; ++rb)
-        for (int cb = k0 / p.bc; cb <= (k1 - 1) / p.bc; ++cb)
-            if (p.bmask[rb * p.nbc + cb]) return true;
-    return false;
-}
 
 template <typename T, int DP, int LD, int NTHREADS>
 __device__ __forceinline__ void ex_load_tile(float* __restrict__ dst, const T* __restrict__ src, int r0, int rows, int n,
@@ -353,21 +313,6 @@ __global__ __launch_bounds__(NW * 64) void ex_dq_kernel(const T* __restrict__ q,
 }
 
 // ---- host launchers
-static ExParams make_params(const ExArgs& a) {
-    ExParams p;
-    p.nq = (int)a.nq; p.nk = (int)a.nk; p.d = (int)a.d;
-    p.causal = a.causal ? 1 : 0;
-    p.coff = (int)(a.nk - a.nq);
-    p.mask = a.mask; p.mask_bh = a.mask_bh_stride;
-    p.bmask = a.block_mask; p.br = (int)(a.br > 0 ? a.br : 1); p.bc = (int)(a.bc > 0 ? a.bc : 1);
-    p.nbc = (int)((a.nk + p.bc - 1) / p.bc);
-    p.p_drop = (float)a.dropout_p;
-    p.keep_scale = a.dropout_p > 0.0 ? (float)(1.0 / (1.0 - a.dropout_p)) : 1.f;
-    p.seed = a.seed;
-    p.scale = a.scale;
-    return p;
-}
-
 template <typename T, int DP, int NW>
 static hipError_t ex_fwd_t(const ExArgs& a, hipStream_t st) {
     constexpr int LD = DP + 4;
@@ -378,7 +323,7 @@ static hipError_t ex_fwd_t(const ExArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(((a.nq + 16 * NW - 1) / (16 * NW)) * a.bh));
     ProfScope ps(K_EX_FWD, st);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v, (T*)a.o, a.lse,
-                       make_params(a));
+                       make_ex_params(a));
     return hipGetLastError();
 }
 
@@ -387,7 +332,7 @@ static hipError_t ex_bwd_t(const ExArgs& a, hipStream_t st) {
     constexpr int LD = DP + 4;
     float* delta = reinterpret_cast<float*>(a.workspace);
     const long long rows = (long long)a.bh * a.nq;
-    const ExParams p = make_params(a);
+    const ExParams p = make_ex_params(a);
     ProfScope ps(K_EX_BWD, st);
     hipLaunchKernelGGL(ex_delta_kernel<T>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, (const T*)a.o,
                        (const T*)a.dout, delta, rows, (int)a.d);
@@ -425,12 +370,24 @@ static hipError_t ex_by_d(const ExArgs& a, bool backward, hipStream_t st) {
 }
 
 hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
+    const int path = option(OPT_EX_PATH);   // 0: MFMA kernels where they apply, 1: always these, 2: MFMA or fail, 3: MFMA, never the plain kernels
+    // no extras at all on a square problem: this IS the plain path — hand it to the tuned kernels (same results contract;
+    // the workspace of fa_ex_backward_workspace_bytes covers their row constants)
+    if ((path == 0 || path == 2) && a.nq == a.nk && !a.mask && !a.block_mask && a.dropout_p <= 0.0 && a.scale > 0.f &&
+        (backward ? bwd_mfma_supported(a.dtype, a.d) : fwd_mfma_supported(a.dtype, a.d))) {
+        if (!backward) return launch_fwd_mfma(FwdArgs{a.q, a.k, a.v, a.o, a.lse, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale}, st);
+        return launch_bwd_mfma(BwdArgs{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale,
+                                       a.workspace, ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
+    }
+    if (path != 1 && ex_mfma_supported(a)) return launch_ex_mfma(a, backward, st);
+    if (path >= 2) return hipErrorInvalidConfiguration;
     switch (a.dtype) {
         case 0: return ex_by_d<float>(a, backward, st);
         case 1: return ex_by_d<__half>(a, backward, st);
         default: return ex_by_d<__hip_bfloat16>(a, backward, st);
     }
 }
-size_t ex_backward_workspace_bytes(int64_t bh, int64_t nq) { return sizeof(float) * (size_t)bh * (size_t)nq + 256; }
+// [-lse/scale | -delta] for the MFMA kernels (the exact kernels keep delta alone in the first half)
+size_t ex_backward_workspace_bytes(int64_t bh, int64_t nq) { return sizeof(float) * 2 * (((size_t)bh * (size_t)nq + 63) & ~(size_t)63) + 256; }
 
 }  // namespace fa

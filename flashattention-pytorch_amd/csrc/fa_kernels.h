@@ -48,7 +48,7 @@ hipError_t ensure_dynamic_smem(const void* kernel, int bytes);
 // Tuning knobs (tile sweep / A-B runs).  Each starts from an environment variable of the same upper-case name with
 // an FA_ prefix (FA_FWD_KB, FA_FWD_STAG, FA_DKDV (4|8), FA_DQ_KT, FA_FWD_RS, FA_DKDV_KREG, FA_FWD_EAGER, FA_FWD_HS, FA_FWD_TPW, FA_DQ_TPW, FA_DKDV_TPW, FA_DQ_NLF, FA_DQ_W4, FA_FWD_ABL, FA_SMALL_GRID, FA_FP8_ROT, FA_DKDV_STG) and can be changed at run time through
 // fa_set_option() so that variants can be interleaved in one process.
-enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_COUNT };
+enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_COUNT };
 int option(int id);
 int set_option(const char* name, int value);   // returns 0, or -1 for an unknown name
 
@@ -82,8 +82,10 @@ size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
 hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
                                 hipStream_t st);
 
-// Extended attention (fa_ex.hip): Nq != Nk with a bottom-right aligned causal mask, dense mask, block-sparse mask,
-// dropout.  Exact-f32 kernels, any dtype, d <= 256.
+// Extended attention: Nq != Nk with a bottom-right aligned causal mask, dense mask, block-sparse mask, dropout.
+// fa_ex.hip: exact-f32 kernels, any dtype, d <= 256.  fa_ex_mfma.hip: bf16 / f16, d % 8 == 0 up to 128, block-sparse
+// blocks that are multiples of 32 — the default where it applies (option ex_path: 1 = always exact f32,
+// 2 = MFMA or fail, 3 = the extended MFMA kernels or fail, also where the plain kernels would do: square, no extras).
 struct ExArgs {
     const void *q, *k, *v;        // q: (bh, nq, d); k, v: (bh, nk, d)
     void* o;                      // (bh, nq, d)
@@ -102,6 +104,8 @@ struct ExArgs {
     void* workspace;              // backward: ex_backward_workspace_bytes
 };
 hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st);
+bool ex_mfma_supported(const ExArgs& a);
+hipError_t launch_ex_mfma(const ExArgs& a, bool backward, hipStream_t st);
 size_t ex_backward_workspace_bytes(int64_t bh, int64_t nq);
 
 }  // namespace fa

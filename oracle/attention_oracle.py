@@ -317,22 +317,28 @@ def attention_flops(bh: int, n: int, d: int, direction: str, causal: bool = Fals
 # the tiled branch's renormalisation by the kept sum, :155-163, is a defect and is not reproduced).
 
 def dropout_keep(bh, nq, nk, p, seed):
-    """(bh, nq, nk) boolean keep mask of the HIP kernels' counter-based generator (csrc/fa_ex.hip: ex_keep): splitmix64 of
-    (seed, element index), the top 24 bits as a uniform in [0, 1), keep iff u > p.  numpy uint64 arithmetic wraps like the
-    device's."""
+    """(bh, nq, nk) boolean keep mask of the HIP kernels' counter-based generator (csrc/fa_ex_common.h: ex_keep): one
+    splitmix64 value per 2 x 2 quad of (row, key) elements — counter (bh * ceil(nq/2) + row//2) << 32 | key//2, plus
+    seed * G + G — and 16 uniform bits per element (field 2 * (row & 1) + (key & 1)); keep iff u >= floor(65536 p) + 1.
+    numpy uint64 arithmetic wraps like the device's."""
     import numpy as np
 
     if p <= 0.0:
         return torch.ones((bh, nq, nk), dtype=torch.bool)
+    thr = int(p * 65536.0) + 1
     with np.errstate(over="ignore"):
-        idx = np.arange(bh * nq * nk, dtype=np.uint64)
+        b = np.arange(bh, dtype=np.uint64)[:, None, None]
+        r = np.arange(nq, dtype=np.uint64)[None, :, None]
+        c = np.arange(nk, dtype=np.uint64)[None, None, :]
+        hi = (b * np.uint64((nq + 1) // 2) + (r >> np.uint64(1))) & np.uint64(0xFFFFFFFF)
         g = np.uint64(0x9E3779B97F4A7C15)
-        z = idx + np.uint64(seed % (1 << 64)) * g + g
+        z = ((hi << np.uint64(32)) | (c >> np.uint64(1))) + np.uint64(seed % (1 << 64)) * g + g
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
-    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return torch.from_numpy((u > np.float32(p)).reshape(bh, nq, nk))
+        field = np.uint64(2) * (r & np.uint64(1)) + (c & np.uint64(1))
+        u = (z >> (np.uint64(16) * field)) & np.uint64(0xFFFF)
+    return torch.from_numpy(u >= np.uint64(thr))
 
 
 def extended_visible(bh, nq, nk, causal=False, mask=None, block_mask=None, br=128, bc=128):

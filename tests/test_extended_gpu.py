@@ -88,6 +88,69 @@ def test_forward_and_backward_match_the_oracle(bh, nq, nk, d, causal, mask_kind,
         assert max_abs(o.cpu(), ro) < 5e-5 and max(max_abs(dq.cpu(), rq), max_abs(dk.cpu(), rk), max_abs(dv.cpu(), rv)) < 2e-4
 
 
+BIG_CASES = [
+    # several 256-row / 128-key tiles per (b,h): tile skipping, the diagonal across tiles, both mask fetch paths
+    (2, 700, 900, 64, True, None, None, 0.0, 0.6),
+    (2, 900, 700, 128, True, None, None, 0.0, 0.6),          # Nq > Nk: the first 200 rows see nothing
+    (1, 600, 1000, 128, False, "shared", None, 0.0, 0.5),    # Nk % 4 == 0: dword mask loads
+    (2, 513, 777, 64, False, "per_bh", None, 0.0, 0.5),      # byte mask loads
+    (1, 1024, 1024, 128, True, None, (128, 128), 0.0, 0.3),  # most tiles dead
+    (1, 800, 1100, 64, False, None, (64, 32), 0.0, 0.2),
+    (2, 520, 640, 128, True, "shared", (32, 32), 0.2, 0.7),  # everything at once
+    (2, 384, 512, 64, False, None, None, 0.5, 0.6),
+    (2, 300, 300, 72, True, None, (96, 160), 0.1, 0.5),      # blocks that do not divide the tiles, padded head dim
+    (2, 640, 640, 128, True, None, None, 0.0, 0.5),          # square, no extras: "mfma" hands this one to the plain kernels
+    (3, 500, 500, 64, False, None, None, 0.0, 0.5),
+]
+
+
+@pytest.mark.parametrize("bh,nq,nk,d,causal,mask_kind,block,p,density", BIG_CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("path", ["mfma", "mfma_only", "exact"])
+def test_multi_tile_cases_on_both_kernel_families(bh, nq, nk, d, causal, mask_kind, block, p, density, dtype, path, device):
+    """16-bit tensors take the MFMA kernels (csrc/fa_ex_mfma.hip) by default; option ex_path pins either family.  Both must
+    match the fp64 oracle, dropout masks included, and mark exactly the rows without a visible key."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do, mask, bmask = _case(bh, nq, nk, d, dtype, seed=77 + nq + nk + d, mask_kind=mask_kind, block=block, density=density)
+    br, bc = block if block is not None else (128, 128)
+    scale, seed = d ** -0.5, 99 + nk
+    kw = dict(causal=causal, softmax_scale=scale, mask=mask, block_mask=bmask, br=br, bc=bc, dropout_p=p, seed=seed)
+    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q, k, v, do, **kw)
+    dev = lambda t: None if t is None else t.to(device)
+    ext.set_option("ex_path", {"mfma": 2, "mfma_only": 3, "exact": 1}[path])   # 3: never the plain kernels
+    try:
+        o, lse = ext.ex_forward(dev(q), dev(k), dev(v), causal, scale, dev(mask), dev(bmask), br, bc, p, seed)
+        dq, dk, dv = ext.ex_backward(dev(q), dev(k), dev(v), o, dev(do), lse, causal, scale, dev(mask), dev(bmask), br, bc, p, seed)
+    finally:
+        ext.set_option("ex_path", 0)
+    tol = dtype_tolerances(dtype)
+    torch.testing.assert_close(o.cpu(), ro, **tol)
+    live = torch.isfinite(rlse)
+    assert torch.equal(torch.isfinite(lse.cpu()), live)
+    torch.testing.assert_close(lse.cpu()[live], rlse[live], rtol=1e-3, atol=1e-3)
+    assert torch.equal(o.cpu()[~live], torch.zeros_like(o.cpu()[~live]))
+    for name, a, b in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert torch.isfinite(a.float()).all(), name
+        torch.testing.assert_close(a.cpu(), b, **tol)
+    assert torch.equal(dq.cpu()[~live], torch.zeros_like(dq.cpu()[~live]))
+
+
+def test_mfma_family_refuses_what_it_does_not_cover(device):
+    import flashattention_lab_cuda as ext
+
+    q = torch.randn((1, 64, 64), device=device)
+    ext.set_option("ex_path", 2)
+    try:
+        with pytest.raises(RuntimeError):
+            ext.ex_forward(q, q, q, False, 0.125)                                   # fp32 tensors
+        with pytest.raises(RuntimeError):
+            h = q.to(torch.bfloat16)
+            ext.ex_forward(h, h, h, False, 0.125, block_mask=torch.ones((2, 2), dtype=torch.uint8, device=device), br=48, bc=48)
+    finally:
+        ext.set_option("ex_path", 0)
+
+
 def test_extras_off_is_the_plain_path_and_dropout_is_reproducible(device):
     """No extras: the extended entry point computes what the plain one does.  Dropout: the same seed gives the same result
     bit for bit (forward and backward), another seed another mask, and E[o] over seeds approaches the undropped o."""

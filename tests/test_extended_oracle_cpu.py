@@ -36,23 +36,26 @@ def test_square_causal_without_extras_is_the_plain_oracle():
         assert (x.double() - y.double()).abs().max().item() < 1e-5
 
 
-def _splitmix_keep(idx, p, seed):
+def _splitmix_keep(bh_i, row, key, nq, p, seed):
+    """the generator of csrc/fa_ex_common.h in Python integers: one splitmix64 value per 2 x 2 quad, 16 bits per element"""
     m = (1 << 64) - 1
     g = 0x9E3779B97F4A7C15
-    z = (idx + seed * g + g) & m
+    ctr = (((bh_i * ((nq + 1) // 2) + row // 2) & 0xFFFFFFFF) << 32) | (key // 2)
+    z = (ctr + seed * g + g) & m
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
     z ^= z >> 31
-    import numpy as np
-    return bool(np.float32(z >> 40) * np.float32(1.0 / 16777216.0) > np.float32(p))
+    u = (z >> (16 * (2 * (row & 1) + (key & 1)))) & 0xFFFF
+    return u >= int(p * 65536.0) + 1
 
 
 def test_dropout_generator_known_answers_and_statistics():
     bh, nq, nk, p, seed = 3, 17, 29, 0.25, 123456789
     keep = orc.dropout_keep(bh, nq, nk, p, seed)
-    flat = keep.flatten().tolist()
-    for idx in (0, 1, 28, 29, 500, bh * nq * nk - 1):
-        assert flat[idx] == _splitmix_keep(idx, p, seed)
+    for b_, r_, c_ in ((0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (0, 0, 28), (1, 16, 5), (2, 16, 28), (2, 7, 13)):
+        assert bool(keep[b_, r_, c_]) == _splitmix_keep(b_, r_, c_, nq, p, seed)
+    # the four fields of one value are used by four different elements, and the value itself is splitmix64's
+    assert _splitmix_keep(0, 0, 0, 2, 0.5, 0) == (((0xE220A8397B1DCDAF >> 0) & 0xFFFF) >= 32769)
     big = orc.dropout_keep(8, 256, 256, 0.3, 7).float().mean().item()
     assert abs(big - 0.7) < 5e-3
     assert torch.equal(orc.dropout_keep(2, 8, 8, 0.5, 9), orc.dropout_keep(2, 8, 8, 0.5, 9))

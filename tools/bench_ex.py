@@ -1,7 +1,8 @@
-"""Forward / backward time of the extended attention path (fa_ex_forward / fa_ex_backward: exact-f32 kernels) per feature,
-with the visible fraction of the score matrix accounted for (algorithmic FLOPs = 4 / 10 x visible (q, key) pairs x d).
+"""Forward / backward time of the extended attention path (fa_ex_forward / fa_ex_backward) per feature and per kernel
+family (16-bit MFMA kernels, csrc/fa_ex_mfma.hip; exact-f32 kernels, csrc/fa_ex.hip), with the visible fraction of the
+score matrix accounted for (algorithmic FLOPs = 4 / 10 x visible (q, key) pairs x d).
 
-    python tools/bench_ex.py [--bh 32] [--nq 2048] [--nk 4096] [--head-dim 128] [--dtype bf16]
+    python tools/bench_ex.py [--bh 32] [--nq 2048] [--nk 4096] [--head-dim 128] [--dtype bf16] [--paths mfma,exact]
 """
 import argparse
 import json
@@ -32,6 +33,8 @@ def main():
     ap.add_argument("--nk", type=int, default=4096)
     ap.add_argument("--head-dim", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--paths", default="mfma,exact")
+    ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     bh, nq, nk, d = args.bh, args.nq, args.nk, args.head_dim
@@ -53,7 +56,11 @@ def main():
         "causal + dropout 0.1": dict(causal=True, dropout_p=0.1, seed=1),
     }
     rows = []
-    for name, kw in cases.items():
+    paths = ["exact"] if args.dtype == "fp32" else args.paths.split(",")
+    for path in paths:
+      ext.set_option("ex_path", 3 if path == "mfma" else 1)   # 3: the extended MFMA kernels even where the plain ones would do
+      for name, kw in cases.items():
+        kw = dict(kw)
         causal = kw.pop("causal", False)
         vis = torch.ones((nq, nk), dtype=torch.bool, device="cuda")
         if causal:
@@ -64,12 +71,14 @@ def main():
             vis &= kw["block_mask"].repeat_interleave(128, 0)[:nq].repeat_interleave(128, 1)[:, :nk] != 0
         frac = vis.float().mean().item()
         o, lse = ext.ex_forward(q, k, v, causal, d ** -0.5, **kw)
-        tf = timed(lambda: ext.ex_forward(q, k, v, causal, d ** -0.5, **kw))
-        tb = timed(lambda: ext.ex_backward(q, k, v, o, do, lse, causal, d ** -0.5, **kw))
+        tf = timed(lambda: ext.ex_forward(q, k, v, causal, d ** -0.5, **kw), args.iters)
+        tb = timed(lambda: ext.ex_backward(q, k, v, o, do, lse, causal, d ** -0.5, **kw), args.iters)
         pairs = bh * nq * nk * frac
-        rows.append(dict(case=name, visible_fraction=round(frac, 4), fwd_ms=round(tf, 3), bwd_ms=round(tb, 3),
+        rows.append(dict(kernels=path, case=name, visible_fraction=round(frac, 4), fwd_ms=round(tf, 3), bwd_ms=round(tb, 3),
                          fwd_tflops=round(4 * pairs * d / tf / 1e9, 2), bwd_tflops=round(10 * pairs * d / tb / 1e9, 2)))
-    print(json.dumps(dict(shape=dict(bh=bh, nq=nq, nk=nk, d=d, dtype=args.dtype), kernels="exact-f32 MFMA (v_mfma_f32_16x16x4_f32), peak 157 TFLOP/s",
+    ext.set_option("ex_path", 0)
+    print(json.dumps(dict(shape=dict(bh=bh, nq=nq, nk=nk, d=d, dtype=args.dtype),
+                          kernels="mfma: v_mfma_f32_32x32x16 (peak 2500 TFLOP/s); exact: v_mfma_f32_16x16x4_f32 (peak 157 TFLOP/s)",
                           rows=rows), indent=1))
 
 
