@@ -94,6 +94,95 @@ __device__ __forceinline__ void dma4_issue_s(rsrc_s_t rsrc, unsigned lds_dst, in
                  :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// Placement of the block's vector work in its 64 MFMA gaps (slice S = the gap behind MFMA S), made by
+// tools/gen_dkdv_schedule.py from the gap budgets: an MFMA leaves the wave about 24 cycles of issue, the operand
+// requests in front of every even MFMA take 8 .. 16 of them.  MUL / EXP: one element of S' -> P; PC: a packed dword of P;
+// SU: a packed dword of dS; ACC: row constants -> an initial accumulator of the next block; DMA: an LDS-DMA piece of the
+// tile three blocks ahead; QADDR / TADDR / LADDR: operand addresses to the next tile's buffer; USE: where hipcc waits
+// for the ACC loads.
+namespace w4sched {
+enum : unsigned char { NONE = 0, OP_MUL, OP_EXP, OP_PC, OP_SU, OP_ACC, OP_LADDR, OP_USE, OP_DMA, OP_QADDR, OP_TADDR };
+struct Op { unsigned char op, a, b; };
+constexpr Op MUL(int kb, int e) { return {OP_MUL, (unsigned char)kb, (unsigned char)e}; }
+constexpr Op EXP(int kb, int e) { return {OP_EXP, (unsigned char)kb, (unsigned char)e}; }
+constexpr Op PC(int kb, int m) { return {OP_PC, (unsigned char)kb, (unsigned char)m}; }
+constexpr Op SU(int kb, int m) { return {OP_SU, (unsigned char)kb, (unsigned char)m}; }
+constexpr Op ACC(int w) { return {OP_ACC, (unsigned char)w, 0}; }
+constexpr Op DMA(int j) { return {OP_DMA, (unsigned char)j, 0}; }
+constexpr Op QADDR(int i) { return {OP_QADDR, (unsigned char)i, 0}; }
+constexpr Op TADDR(int j) { return {OP_TADDR, (unsigned char)j, 0}; }
+constexpr Op LADDR{OP_LADDR, 0, 0}, USE{OP_USE, 0, 0};
+constexpr int kWidth = 5;
+// generated by tools/gen_dkdv_schedule.py: 0 cycles over budget in 0 gaps
+// slice S (after MFMA S): up to 5 operations
+constexpr Op kSched[64][kWidth] = {
+    /*  0 (24) */ {DMA(0)},
+    /*  1 ( 8) */ {LADDR},
+    /*  2 (24) */ {DMA(1)},
+    /*  3 ( 8) */ {},
+    /*  4 (24) */ {DMA(2)},
+    /*  5 ( 8) */ {},
+    /*  6 (24) */ {DMA(3)},
+    /*  7 ( 8) */ {},
+    /*  8 (24) */ {DMA(4)},
+    /*  9 (16) */ {},
+    /* 10 (24) */ {QADDR(0)},
+    /* 11 (16) */ {},
+    /* 12 (24) */ {QADDR(1)},
+    /* 13 (16) */ {},
+    /* 14 (24) */ {QADDR(2)},
+    /* 15 (16) */ {},
+    /* 16 (24) */ {MUL(0,0), EXP(0,0), MUL(0,1), EXP(0,1)},
+    /* 17 (16) */ {MUL(0,2), EXP(0,2), MUL(0,3)},
+    /* 18 (24) */ {EXP(0,3), MUL(0,4), EXP(0,4), MUL(0,5)},
+    /* 19 (16) */ {EXP(0,5), MUL(0,6), MUL(0,7)},
+    /* 20 (24) */ {EXP(0,6), EXP(0,7), PC(0,0), PC(0,1)},
+    /* 21 (16) */ {PC(0,2), PC(0,3), MUL(1,0), MUL(1,1)},
+    /* 22 (24) */ {EXP(1,0), EXP(1,1), MUL(1,2), MUL(1,3)},
+    /* 23 (16) */ {EXP(1,2), EXP(1,3)},
+    /* 24 (24) */ {MUL(1,4), EXP(1,4), MUL(1,5), EXP(1,5)},
+    /* 25 (12) */ {MUL(1,6), EXP(1,6)},
+    /* 26 (24) */ {MUL(1,7), EXP(1,7), PC(1,0), PC(1,1), PC(1,2)},
+    /* 27 (12) */ {PC(1,3), MUL(0,8), MUL(0,9)},
+    /* 28 (24) */ {EXP(0,8), EXP(0,9), MUL(0,10), MUL(0,11)},
+    /* 29 (12) */ {EXP(0,10), MUL(0,12)},
+    /* 30 (24) */ {EXP(0,11), EXP(0,12), MUL(0,13), MUL(0,14)},
+    /* 31 (12) */ {EXP(0,13), MUL(0,15)},
+    /* 32 (24) */ {EXP(0,14), EXP(0,15), PC(0,4), PC(0,5)},
+    /* 33 (12) */ {PC(0,6), PC(0,7), MUL(1,8)},
+    /* 34 (24) */ {EXP(1,8), MUL(1,9), EXP(1,9), MUL(1,10)},
+    /* 35 (12) */ {EXP(1,10), MUL(1,11)},
+    /* 36 (24) */ {EXP(1,11), MUL(1,12), EXP(1,12), MUL(1,13)},
+    /* 37 (12) */ {EXP(1,13), MUL(1,14)},
+    /* 38 (24) */ {EXP(1,14), MUL(1,15), EXP(1,15), PC(1,4)},
+    /* 39 (12) */ {PC(1,5), PC(1,6), PC(1,7)},
+    /* 40 (24) */ {SU(0,0), SU(0,1)},
+    /* 41 (12) */ {SU(0,2)},
+    /* 42 (24) */ {SU(0,3), SU(1,0)},
+    /* 43 (12) */ {SU(1,1)},
+    /* 44 (24) */ {SU(1,2), SU(1,3)},
+    /* 45 (12) */ {SU(0,4)},
+    /* 46 (24) */ {SU(0,5), SU(0,6)},
+    /* 47 (12) */ {SU(0,7)},
+    /* 48 (24) */ {SU(1,4), SU(1,5)},
+    /* 49 (12) */ {SU(1,6)},
+    /* 50 (24) */ {SU(1,7), QADDR(3), QADDR(4), QADDR(5)},
+    /* 51 (12) */ {QADDR(6), QADDR(7)},
+    /* 52 (24) */ {ACC(0)},
+    /* 53 (12) */ {},
+    /* 54 (24) */ {ACC(2)},
+    /* 55 (12) */ {},
+    /* 56 (24) */ {ACC(1), TADDR(0)},
+    /* 57 ( 8) */ {TADDR(1)},
+    /* 58 (24) */ {ACC(3), TADDR(2)},
+    /* 59 ( 8) */ {TADDR(3)},
+    /* 60 (24) */ {},
+    /* 61 ( 8) */ {},
+    /* 62 (24) */ {USE},
+    /* 63 ( 8) */ {},
+};
+}  // namespace w4sched
+
 template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1)>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
@@ -220,14 +309,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     };
     auto block = [&](int blk) {
         const int dlt = ((blk + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
-        // Vector work, cut to fit the MFMA gaps (an MFMA leaves ~24 of its 32 cycles of vector issue to the wave; prices
-        // in MI355X_MICROARCH.md: v_exp 8, the rest 4).  PE: one element of S' -> exp2 (2 instructions);  PC: one packed
-        // dword of P from two finished elements (placed one gap after its exp2's: no dependency stall, no hazard nop);
+        // Vector work, cut into single instructions' worth and placed by the table above (w4sched::kSched): MUL + EXP: one
+        // element of S' -> P = exp2(c S') in place (the f32 P is what dS is made from, as in the dQ kernel);  PC: one packed
+        // dword of P from two finished elements (at least one gap behind its exp2's: no dependency stall, no hazard nop);
         // SU: one packed dword of dS = P dP' (f32 P, one rounding).
-        auto PE = [&](auto kbc, auto ic) {   // in place: the f32 P is what dS is made from (as in the dQ kernel)
-            constexpr int kb = decltype(kbc)::value, i = decltype(ic)::value;
-            sacc[kb][i] = __builtin_amdgcn_exp2f(sacc[kb][i] * c_log2);
-        };
         auto PC = [&](auto kbc, auto mc) {
             constexpr int kb = decltype(kbc)::value, m = decltype(mc)::value;
             pp[kb][m >> 2][m & 3] = pack2<Tag>(sacc[kb][2 * m], sacc[kb][2 * m + 1]);
@@ -237,47 +322,32 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             sp[kb][m >> 2][m & 3] = pack2<Tag>(sacc[kb][2 * m] * pacc[kb][2 * m], sacc[kb][2 * m + 1] * pacc[kb][2 * m + 1]);
         };
         using std::integral_constant;
-        // The vector work that follows MFMA S of the block (S = 0 .. 63).  Deadlines: P[kb][s] feeds MFMAs 32 + 8 s ...,
-        // dS[kb][s] feeds MFMAs 48 + 8 s ...; S' is complete after MFMA 15, dP' after MFMA 31, and a consumer sits at
-        // least two MFMAs behind the chain it reads (hipcc pads nothing around the asm MFMAs).
+        // The work that follows MFMA S of the block (S = 0 .. 63).  The table keeps the deadlines — P[kb][s] feeds MFMAs
+        // 32 + 8 s ..., dS[kb][s] MFMAs 48 + 8 s ...; S'[kb] is complete after MFMA 14 + kb, dP'[kb] after MFMA 30 + kb, and a
+        // consumer sits at least two MFMAs behind the chain it reads (hipcc pads nothing around the asm MFMAs;
+        // tools/mfma_hazard_audit.py checks the built code) — and every gap within its issue budget: 42.1 -> 39.3 cycles per
+        // MFMA against the first hand placement, bitwise the same results (profiles/r02_cycles_dkdv.md).
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr ((ABL & 1) && S >= 17 && S <= 48) {}
-            else if constexpr ((ABL & 2) && S >= 53 && S <= 57) {}
-            else if constexpr ((ABL & 8) && S >= 49 && S <= 52) {}
-            else if constexpr ((ABL & 16) && (S == 48 || S >= 53)) {}
-            else if constexpr (S >= 17 && S <= 33) {
-                // pair u = S - 17 (kb = u / 8, m = u % 8): its two exp2's; the pack of pair u - 1 goes first
-                constexpr int u = S - 17;
-                if constexpr (u >= 1) PC(integral_constant<int, (u - 1) / 8>{}, integral_constant<int, (u - 1) % 8>{});
-                if constexpr (u < 16) {
-                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8)>{});
-                    PE(integral_constant<int, u / 8>{}, integral_constant<int, 2 * (u % 8) + 1>{});
-                }
-                if constexpr (S == 33) SU(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            {   // ABL bits: see the kernel's header comment
+                for_each_const([&](auto jc) {
+                    constexpr w4sched::Op o = w4sched::kSched[S][decltype(jc)::value];
+                    constexpr int a = o.a, b = o.b;
+                    if constexpr (o.op == w4sched::OP_MUL && !(ABL & 1)) sacc[a][b] *= c_log2;
+                    else if constexpr (o.op == w4sched::OP_EXP && !(ABL & 1)) sacc[a][b] = __builtin_amdgcn_exp2f(sacc[a][b]);
+                    else if constexpr (o.op == w4sched::OP_PC && !(ABL & 1)) PC(integral_constant<int, a>{}, integral_constant<int, b>{});
+                    else if constexpr (o.op == w4sched::OP_SU && !(ABL & 1)) SU(integral_constant<int, a>{}, integral_constant<int, b>{});
+                    else if constexpr (o.op == w4sched::OP_ACC && !(ABL & 8)) {
+                        if constexpr (a < 2) lds_acc_init<0>(laddr, sacc[a]);
+                        else lds_acc_init<256>(laddr, pacc[a - 2]);
+                    }
+                    else if constexpr (o.op == w4sched::OP_USE && !(ABL & 8)) asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(pacc[0]), "+v"(pacc[1]));
+                    else if constexpr (o.op == w4sched::OP_DMA && !(ABL & 2)) dma_piece(integral_constant<int, a>{}, blk + 3);
+                    else if constexpr (o.op == w4sched::OP_LADDR && !(ABL & 16)) laddr += dlt;
+                    else if constexpr (o.op == w4sched::OP_QADDR && !(ABL & 16)) qaddr[a] += dlt;
+                    else if constexpr (o.op == w4sched::OP_TADDR && !(ABL & 16)) { tlo[a] += dlt; thi[a] += dlt; }
+                }, std::make_integer_sequence<int, w4sched::kWidth>{});
             }
-            // one dS dword per gap: key block 0 / 1 of k-step s = 0 (MFMAs 48 ...), then of s = 1 (MFMAs 56 ...)
-            else if constexpr (S >= 34 && S <= 36) SU(integral_constant<int, 0>{}, integral_constant<int, S - 33>{});
-            else if constexpr (S >= 37 && S <= 40) SU(integral_constant<int, 1>{}, integral_constant<int, S - 37>{});
-            else if constexpr (S >= 41 && S <= 44) SU(integral_constant<int, 0>{}, integral_constant<int, S - 37>{});
-            else if constexpr (S >= 45 && S <= 48) {
-                SU(integral_constant<int, 1>{}, integral_constant<int, S - 41>{});
-                if constexpr (S == 48) laddr += dlt;
-            }
-            // the next block's row constants become the initial accumulators (S' / P and dP' are free after MFMA 48)
-            else if constexpr (S == 49) lds_acc_init<0>(laddr, sacc[0]);
-            else if constexpr (S == 50) lds_acc_init<0>(laddr, sacc[1]);
-            else if constexpr (S == 51) lds_acc_init<256>(laddr, pacc[0]);
-            else if constexpr (S == 52) lds_acc_init<256>(laddr, pacc[1]);
-            else if constexpr (S >= 53 && S <= 57) {
-                dma_piece(integral_constant<int, S - 53>{}, blk + 3);
-                qaddr[S - 53] += dlt;                                   // dO rows were last requested at MFMA 24
-                if constexpr (S >= 55) qaddr[S - 50] += dlt;            // 5, 6, 7
-            } else if constexpr (S == 59) {
-                // hipcc waits for its row-constant loads at their first use: give it one here, where few operand requests
-                // are in flight, instead of the head of the next block's chains (its wait drains our requests too)
-                asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(pacc[0]), "+v"(pacc[1]));
-            } else if constexpr (S >= 60) { tlo[S - 60] += dlt; thi[S - 60] += dlt; }   // last transposed request: MFMA 56
         };
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value, ph = g / 8, i = g % 8, s0 = G::slot(g);

@@ -105,6 +105,79 @@ __device__ __forceinline__ void dq_dma16_issue_s(rsrc_s_t rsrc, unsigned lds_dst
                  :: "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// Placement of an iteration's vector work in its 48 MFMA gaps (slice S = the gap behind MFMA S), made by
+// tools/gen_dq_schedule.py from the gap budgets (an MFMA leaves the wave about 24 cycles of issue and 5 instructions; the
+// operand requests in front of the even MFMAs take their share).  FMA / EXP(h, e): one element of P^T = exp2(c S^T - lse),
+// h = 0: block b, rows 32 .. 63; h = 1: block b + 1, rows 0 .. 31;  EXPL(e): the exp2 the previous iteration left over
+// (its tail is the fullest part of an iteration, the head the emptiest);  SM(qb, e): one element of dS^T = P^T (dP^T - delta),
+// in place;  SC(qb, m): a packed dword of dS^T;  DMA(j): an LDS-DMA piece of the tile three ahead;  KADDR / TADDR: operand
+// addresses to the next tile's buffer (second block of a tile only).
+namespace dqsched {
+enum : unsigned char { NONE = 0, OP_FMA, OP_EXP, OP_EXPL, OP_SM, OP_SC, OP_DMA, OP_KADDR, OP_TADDR };
+struct Op { unsigned char op, a, b; };
+constexpr Op FMA(int h, int e) { return {OP_FMA, (unsigned char)h, (unsigned char)e}; }
+constexpr Op EXP(int h, int e) { return {OP_EXP, (unsigned char)h, (unsigned char)e}; }
+constexpr Op EXPL(int e) { return {OP_EXPL, 0, (unsigned char)e}; }
+constexpr Op SM(int qb, int e) { return {OP_SM, (unsigned char)qb, (unsigned char)e}; }
+constexpr Op SC(int qb, int m) { return {OP_SC, (unsigned char)qb, (unsigned char)m}; }
+constexpr Op DMA(int j) { return {OP_DMA, (unsigned char)j, 0}; }
+constexpr Op KADDR(int i) { return {OP_KADDR, (unsigned char)i, 0}; }
+constexpr Op TADDR(int j) { return {OP_TADDR, (unsigned char)j, 0}; }
+constexpr int kWidth = 5, kLate = 4;   // kLate: elements 16 - kLate .. 15 of P^T(b + 1), rows 0 .. 31, get their exp2 in the next iteration
+// generated by tools/gen_dq_schedule.py: 0 cycles over budget in 0 gaps, 0 gaps over 5 instructions
+// slice S (after MFMA S): up to 5 operations
+constexpr Op kSched[48][kWidth] = {
+    /*  0 (24) */ {EXPL(12), EXPL(13), EXPL(14)},
+    /*  1 (20) */ {EXPL(15), KADDR(0), KADDR(1), KADDR(2)},
+    /*  2 (24) */ {KADDR(3), DMA(0)},
+    /*  3 (16) */ {KADDR(4), FMA(0,0), FMA(0,1)},
+    /*  4 (24) */ {DMA(1), KADDR(5)},
+    /*  5 (20) */ {DMA(2)},
+    /*  6 (24) */ {DMA(3), KADDR(6)},
+    /*  7 (16) */ {FMA(0,2), FMA(0,3), FMA(0,4)},
+    /*  8 (24) */ {KADDR(7), FMA(0,5), FMA(0,6), FMA(0,7), FMA(0,8)},
+    /*  9 (20) */ {FMA(0,9), FMA(0,10), FMA(0,11), FMA(0,12)},
+    /* 10 (24) */ {FMA(0,13), FMA(0,14), FMA(0,15), EXP(0,0)},
+    /* 11 (16) */ {EXP(0,1), EXP(0,2)},
+    /* 12 (24) */ {EXP(0,3), EXP(0,4), EXP(0,5)},
+    /* 13 (20) */ {EXP(0,6), EXP(0,7)},
+    /* 14 (24) */ {EXP(0,8), EXP(0,9), EXP(0,10)},
+    /* 15 (16) */ {EXP(0,11), EXP(0,12)},
+    /* 16 (24) */ {SM(0,0), SM(0,1), EXP(0,13)},
+    /* 17 (20) */ {SM(0,2), SM(0,3)},
+    /* 18 (24) */ {SM(0,4), SM(0,5), SC(0,0)},
+    /* 19 (16) */ {SM(0,6), SC(0,1)},
+    /* 20 (24) */ {SM(0,7), SC(0,2), SM(1,0)},
+    /* 21 (20) */ {SC(0,3), SM(1,1), EXP(0,14)},
+    /* 22 (24) */ {SM(1,2), SM(1,3), SC(1,0)},
+    /* 23 (16) */ {SM(1,4), SC(1,1)},
+    /* 24 (24) */ {SM(1,5), SM(1,6), EXP(0,15)},
+    /* 25 (16) */ {SM(1,7), SC(1,2)},
+    /* 26 (24) */ {SC(1,3), SM(0,8), SM(0,9)},
+    /* 27 (12) */ {SM(0,10)},
+    /* 28 (24) */ {SM(0,11), SM(0,12), SC(0,4)},
+    /* 29 (16) */ {SM(0,13), SC(0,5)},
+    /* 30 (24) */ {SM(0,14), SM(0,15), SC(0,6)},
+    /* 31 (12) */ {SC(0,7)},
+    /* 32 (24) */ {SM(1,8), SM(1,9), FMA(1,0)},
+    /* 33 (16) */ {SM(1,10), SC(1,4)},
+    /* 34 (24) */ {TADDR(0), SM(1,11), FMA(1,1)},
+    /* 35 (12) */ {SM(1,12)},
+    /* 36 (24) */ {SM(1,13), SM(1,14), SC(1,5)},
+    /* 37 (16) */ {SM(1,15), SC(1,6)},
+    /* 38 (24) */ {TADDR(1), SC(1,7), TADDR(2)},
+    /* 39 (12) */ {FMA(1,2), FMA(1,3)},
+    /* 40 (24) */ {TADDR(3), FMA(1,4), FMA(1,5), FMA(1,6)},
+    /* 41 (20) */ {FMA(1,7), FMA(1,8), FMA(1,9), FMA(1,10)},
+    /* 42 (24) */ {FMA(1,11), FMA(1,12), FMA(1,13), FMA(1,14), FMA(1,15)},
+    /* 43 (16) */ {EXP(1,0), EXP(1,1)},
+    /* 44 (24) */ {EXP(1,2), EXP(1,3), EXP(1,4)},
+    /* 45 (20) */ {EXP(1,5), EXP(1,6)},
+    /* 46 (24) */ {EXP(1,7), EXP(1,8), EXP(1,9)},
+    /* 47 (16) */ {EXP(1,10), EXP(1,11)},
+};
+}  // namespace dqsched
+
 // ABL != 0: profiling ablations (wrong results on purpose; option dq_abl):
 //   bit 0: no vector slices   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no operand requests
 //   bit 5: shader-clock stamps around the tile loop; wave 0 of workgroup 0 overwrites dq[0..7] with (cycles, tiles)
@@ -275,46 +348,41 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
     //   g = 16 .. 23  dQ^T[qb][db] += K(b)^T[s][db] dS^T(b)[qb][s]     request: two transposed 4-row blocks of K
     // and the vector work rides in their gaps: the second half of P^T(b) = exp2(c S^T(b) - lse) under the dP^T chains,
     // dS^T(b) = P^T (dP^T - delta) under the S^T(b+1) chains (which use the other pair of S accumulators), the first half
-    // of P^T(b+1) under the dQ^T products.  One pair per gap at most: the matrix pipe sets the pace.
+    // of P^T(b+1) under the dQ^T products — instruction by instruction as dqsched::kSched places them.
     auto iter = [&](auto kbc, int t) {   // t: key tile (relative to the query tile), KB: 32-key block b in it
         constexpr int KB = decltype(kbc)::value, CUR = KB, NXT = 1 - KB;   // S accumulator pairs of blocks b and b + 1
         const int dlt = ((gtile + t + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
         using std::integral_constant;
-        auto PE = [&](auto setc, auto qbc, auto ic) {   // in place: S^T becomes P^T
-            constexpr int st = decltype(setc)::value, qb = decltype(qbc)::value, i = decltype(ic)::value;
-            sacc[st][qb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[st][qb][i], c_log2, nl2[qb]));
-        };
-        auto SU = [&](auto qbc, auto mc) {   // one packed dword of dS^T = P^T (dP^T - delta)
-            constexpr int qb = decltype(qbc)::value, m = decltype(mc)::value;
-            dsb[qb][m >> 2][m & 3] = pack2<Tag>(sacc[CUR][qb][2 * m] * (pacc[qb][2 * m] + nd[qb]),
-                                                sacc[CUR][qb][2 * m + 1] * (pacc[qb][2 * m + 1] + nd[qb]));
-        };
-        // the vector work that follows MFMA S of the iteration (S = 0 .. 47).  dP^T(b) is complete after MFMA 15,
-        // S^T(b+1) after MFMA 31; dS^T(b)[.][s] feeds MFMAs 32 + 8 s ...; a consumer sits at least two MFMAs behind the
-        // chain it reads (hipcc pads nothing around the asm MFMAs; tools/mfma_hazard_audit.py checks the distances).
+        // the work that follows MFMA S of the iteration (S = 0 .. 47), from the table above.  dP^T(b)[qb] is complete after
+        // MFMA 14 + qb, S^T(b+1)[qb] after MFMA 30 + qb; dS^T(b)[.][s] feeds MFMAs 32 + 8 s ...; a consumer sits at least
+        // two MFMAs behind the chain it reads (hipcc pads nothing around the asm MFMAs; tools/mfma_hazard_audit.py checks).
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr (ABL & 1) {}
-            else if constexpr (S < 16) {
-                PE(integral_constant<int, CUR>{}, integral_constant<int, 1>{}, integral_constant<int, S>{});   // P^T(b), rows 32 ..
-                if constexpr (KB == 1 && (S == 8 || S == 9)) {   // V rows of this tile were last requested at MFMA 8
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) kaddr[4 * (S - 8) + j] += dlt;
+            for_each_const([&](auto jc) {
+                constexpr dqsched::Op o = dqsched::kSched[S][decltype(jc)::value];
+                constexpr int a = o.a, e = o.b;
+                // h = 0: P^T(b), rows 32 .. 63 -> sacc[CUR][1];  h = 1: P^T(b + 1), rows 0 .. 31 -> sacc[NXT][0]
+                if constexpr (o.op == dqsched::OP_FMA && !(ABL & 1)) {
+                    if constexpr (a == 0) sacc[CUR][1][e] = fmaf(sacc[CUR][1][e], c_log2, nl2[1]);
+                    else sacc[NXT][0][e] = fmaf(sacc[NXT][0][e], c_log2, nl2[0]);
+                } else if constexpr (o.op == dqsched::OP_EXP && !(ABL & 1)) {
+                    if constexpr (a == 0) sacc[CUR][1][e] = __builtin_amdgcn_exp2f(sacc[CUR][1][e]);
+                    else sacc[NXT][0][e] = __builtin_amdgcn_exp2f(sacc[NXT][0][e]);
+                } else if constexpr (o.op == dqsched::OP_EXPL && !(ABL & 1)) {
+                    sacc[CUR][0][e] = __builtin_amdgcn_exp2f(sacc[CUR][0][e]);
+                } else if constexpr (o.op == dqsched::OP_SM && !(ABL & 1)) {
+                    sacc[CUR][a][e] *= pacc[a][e] + nd[a];          // P^T(b) is dead behind its dS^T: in place
+                } else if constexpr (o.op == dqsched::OP_SC && !(ABL & 1)) {
+                    dsb[a][e >> 2][e & 3] = pack2<Tag>(sacc[CUR][a][2 * e], sacc[CUR][a][2 * e + 1]);
+                } else if constexpr (o.op == dqsched::OP_DMA && !(ABL & 2)) {
+                    dma_piece(integral_constant<int, 4 * KB + a>{}, t + 3);
+                } else if constexpr (o.op == dqsched::OP_KADDR && KB == 1 && !(ABL & 1)) {
+                    kaddr[a] += dlt;     // V rows of this tile: last requested in front of MFMA 2 (a - 3); K rows of the next: MFMA 10 + 2 a
+                } else if constexpr (o.op == dqsched::OP_TADDR && KB == 1 && !(ABL & 1)) {
+                    tlo[a] += dlt;       // last transposed request of the tile: in front of MFMA 34 + 2 a
+                    thi[a] += dlt;
                 }
-            } else if constexpr (S >= 17 && S <= 32) {
-                // pairs in the order the dQ^T products need them: (qb 0, s 0) x4, (qb 1, s 0) x4, (qb 0, s 1) x4, (qb 1, s 1) x4
-                constexpr int u = S - 17, qb = (u / 4) & 1, m = 4 * (u / 8) + (u % 4);
-                SU(integral_constant<int, qb>{}, integral_constant<int, m>{});
-                if constexpr (!(ABL & 2) && (S == 21 || S == 23 || S == 25 || S == 27))
-                    dma_piece(integral_constant<int, 4 * KB + (S - 21) / 2>{}, t + 3);
-                if constexpr (S == 32) PE(integral_constant<int, NXT>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-            } else if constexpr (S >= 33 && S <= 47) {
-                PE(integral_constant<int, NXT>{}, integral_constant<int, 0>{}, integral_constant<int, S - 32>{});   // P^T(b+1), rows 0 ..
-                if constexpr (KB == 1 && S >= 41 && S <= 44) {   // last transposed request: MFMA 40
-                    tlo[S - 41] += dlt;
-                    thi[S - 41] += dlt;
-                }
-            }
+            }, std::make_integer_sequence<int, dqsched::kWidth>{});
         };
         auto group = [&](auto gc) {
             constexpr int g = decltype(gc)::value, ph = g / 8, i = g % 8, s0 = G::slot(g);
@@ -394,9 +462,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
             ring[G::slot(g)] = lds_b128_asm<KT>(kaddr[g]);
         }, std::make_integer_sequence<int, AHEAD>{});
         asm volatile("s_nop 15" : "+v"(sacc[0][0]), "+v"(sacc[0][1]));
-        if (!(ABL & 1)) {
+        if (!(ABL & 1)) {   // what an iteration does for block b + 1; the last kLate exp2's belong to the next iteration
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[0][0][i] = __builtin_amdgcn_exp2f(fmaf(sacc[0][0][i], c_log2, nl2[0]));
+            for (int i = 0; i < 16; ++i) {
+                const float x = fmaf(sacc[0][0][i], c_log2, nl2[0]);
+                sacc[0][0][i] = i < 16 - dqsched::kLate ? __builtin_amdgcn_exp2f(x) : x;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
