@@ -94,21 +94,35 @@ __device__ __forceinline__ unsigned mask_load_b32(const MaskSrc& m, int off) { r
 __device__ __forceinline__ unsigned mask_load_b8(const MaskSrc& m, int off) { return (unsigned)(__builtin_amdgcn_raw_buffer_load_b8(m.rs, off, 0, 0) & 0xff); }
 
 // 16-bit visibility mask (bit i = register i visible) of one 32 x 32 block for a lane of a query-on-the-lane kernel:
-// the lane's row is `row`, register i holds key kb0 + 4 h + rc(i)
-__device__ __forceinline__ unsigned dense_bits_q(const MaskSrc& m, int row, int nk, int kcol) {
+// the lane's row is `row`, register i holds key kcol + rc(i)
+__device__ __forceinline__ void mask_words_q(const MaskSrc& m, int row, int nk, int kcol, unsigned (&wd)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wd[g] = mask_load_b32(m, row * nk + kcol + 8 * g);
+}
+__device__ __forceinline__ unsigned bits_of_words(const unsigned (&wd)[4]) {
+    // Structured masks (a causal or windowed mask handed over as a dense one) are all-visible or all-masked over most
+    // 32 x 32 blocks: two wave-uniform tests on the words save the per-byte work there (6 instructions per element)
+    unsigned zero_byte = 0;   // bit 7 of every byte that is 0
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zero_byte |= (wd[g] - 0x01010101u) & ~wd[g] & 0x80808080u;
+    if (__all(zero_byte == 0)) return 0xffffu;
+    if (__all((wd[0] | wd[1] | wd[2] | wd[3]) == 0)) return 0u;
     unsigned bits = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits |= ((wd[g] >> (8 * j)) & 0xffu) ? (1u << (4 * g + j)) : 0u;
+    return bits;
+}
+__device__ __forceinline__ unsigned dense_bits_q(const MaskSrc& m, int row, int nk, int kcol) {
     if (m.dwords) {
         unsigned wd[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) wd[g] = mask_load_b32(m, row * nk + kcol + 8 * g);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bits |= ((wd[g] >> (8 * j)) & 0xffu) ? (1u << (4 * g + j)) : 0u;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bits |= mask_load_b8(m, row * nk + kcol + rc_of(i)) ? (1u << i) : 0u;
+        mask_words_q(m, row, nk, kcol, wd);
+        return bits_of_words(wd);
     }
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bits |= mask_load_b8(m, row * nk + kcol + rc_of(i)) ? (1u << i) : 0u;
     return bits;
 }
 // the same for a lane of the key-on-the-lane kernel: the lane's key is `key`, register i holds row rb0 + 4 h + rc(i)
@@ -210,8 +224,9 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
     // two loops instead of an `if` inside one (a conditional accumulate makes hipcc carry the accumulators through
     // copies): tiles this wave computes, then the ones it only helps to load
     // Dense mask: its loads are ordinary VMEM loads, and VMEM returns in order — were the next tile's LDS-DMA issued
-    // first, the wait for the mask words would also be a wait for that whole tile.  So the DMA goes out after the mask
-    // has been applied (it still has the P.V half of the tile to land).
+    // first, the wait for the mask words would also be a wait for that whole tile.  So the DMA goes out when the mask has
+    // been read (it still has the tile's products to land).  Fetching the words a tile ahead instead (16 more live
+    // registers) was measured slower: 1.15 vs 1.08 ms forward at BH 64, N 4096, half the pairs masked.
     const bool late_stage = (FEAT & kFeatMask) && msk.on;
     while (t < ntiles_w) {
         const int tn = next_live(t + 1);
@@ -234,6 +249,17 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
                     if (drop) kp[kb] = keep_bits_q(p, hi, qrow, k0 + 32 * kb + 4 * h);
                 }
             }
+            // a tile of which this wave sees nothing (the upper triangle of a causal mask handed over as a dense one, the
+            // dead blocks of a block-sparse tile) is not computed: wave-uniform
+            bool any_vis = true;
+            if constexpr (FEAT & kFeatMask) {
+                unsigned all = 0;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) all |= vis[kb];
+                any_vis = __any(all != 0) != 0;
+                if (late_stage && tn < ntiles) stage(cur ^ 1, tn * BN);   // the mask words have arrived
+            }
+            if (any_vis) {
             f32x16 sacc[KB];
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
@@ -260,10 +286,11 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
             if constexpr (FEAT & kFeatMask) {
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
+                    if (__any(vis[kb] != 0xffffu)) {   // wave-uniform
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (!((vis[kb] >> i) & 1u)) sacc[kb][i] = -INFINITY;
-                if (late_stage && tn < ntiles) stage(cur ^ 1, tn * BN);
+                        for (int i = 0; i < 16; ++i)
+                            if (!((vis[kb] >> i) & 1u)) sacc[kb][i] = -INFINITY;
+                    }
             }
             // ---- online softmax (fa_fwd_mfma.hip), with rows that have not met a visible key yet (m = -inf)
             float mx = sacc[0][0];
@@ -317,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
                 }
             }
             l_run += rs;
+            }   // any_vis
         }
         dma_wait_all();
         __syncthreads();
@@ -469,6 +497,8 @@ __global__ __launch_bounds__(512, 2) void exm_dkdv_kernel(const uint16_t* __rest
             if constexpr (FEAT & kFeatDrop) {
                 if (drop) kp = keep_bits_k(p, (unsigned)bh * p.nqh, rb0 + 4 * h, key);
             }
+            // a block of which this wave sees nothing is not computed (wave-uniform; see the forward kernel)
+            if ((FEAT & kFeatMask) && !__any(vis != 0)) continue;
             // masked: the row precedes the key's first visible row (causal), or the key lies past nk: rc(i) < thr
             const bool need_mask = (p.causal && (kw0 + 31 - p.coff > rb0)) || (kw0 + 32 > nk);
             const int thr = !need_mask ? -1 : (key >= nk ? 64 : (p.causal ? key - p.coff - rb0 - 4 * h : -1));
@@ -491,11 +521,18 @@ __global__ __launch_bounds__(512, 2) void exm_dkdv_kernel(const uint16_t* __rest
                     const s16x8 kf = *reinterpret_cast<const s16x8*>(Ks + ro + kofs);
                     sacc = mfma32<Tag>(qa, kf, sacc);
                 }
+                // wave-uniform: blocks that every lane sees whole (most of a structured mask) skip the selects
+                const bool plain = !need_mask && (!(FEAT & kFeatMask) || !__any(vis != 0xffffu));
+                if (plain) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    bool dead = rc_of(i) < thr;
-                    if constexpr (FEAT & kFeatMask) dead = dead || !((vis >> i) & 1u);
-                    sacc[i] = dead ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                    for (int i = 0; i < 16; ++i) sacc[i] = __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        bool dead = rc_of(i) < thr;
+                        if constexpr (FEAT & kFeatMask) dead = dead || !((vis >> i) & 1u);
+                        sacc[i] = dead ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2);
+                    }
                 }
                 if constexpr (FEAT & kFeatDrop) {
 #pragma unroll
@@ -657,13 +694,16 @@ __global__ __launch_bounds__(512, 2) void exm_dq_kernel(const uint16_t* __restri
                 visw[1] = dense_bits_q(msk, qrow, nk, k0 + 32 + 4 * h);
                 if (tn < ntiles) stage(cur ^ 1, tn * BN);
             }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                if (use_bm && p.bmask[rbw * p.nbc + min(k0 + 32 * kb, nk - 1) / p.bc] == 0) visw[kb] = 0;
         }
+        // a tile of which this wave sees nothing is not computed (wave-uniform; see the forward kernel)
+        const bool any_vis = !(FEAT & kFeatMask) || __any((visw[0] | visw[1]) != 0) != 0;
+        if (any_vis) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             unsigned vis = visw[kb], kp = 0xffffu;
-            if constexpr (FEAT & kFeatMask) {
-                if (use_bm && p.bmask[rbw * p.nbc + min(k0 + 32 * kb, nk - 1) / p.bc] == 0) vis = 0;
-            }
             if constexpr (FEAT & kFeatDrop) {
                 if (drop) kp = keep_bits_q(p, hi, qrow, k0 + 32 * kb + 4 * h);
             }
@@ -681,13 +721,24 @@ __global__ __launch_bounds__(512, 2) void exm_dq_kernel(const uint16_t* __restri
             const bool need_mask = (p.causal && (k0 + 32 * kb + 31 > q0 + 32 * w + p.coff)) || (k0 + 32 * kb + 32 > nk);
             const int lim = p.causal ? min(qrow + p.coff, nk - 1) : nk - 1;
             const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+            // wave-uniform (not in the dropout build: two copies of its selects cost registers it does not have)
+            const bool plain = !(FEAT & kFeatDrop) && !need_mask && (!(FEAT & kFeatMask) || !__any(vis != 0xffffu));
+            if (plain) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                bool dead = rc_of(i) > thr;
-                if constexpr (FEAT & kFeatMask) dead = dead || !((vis >> i) & 1u);
-                float dpv = pacc[i];
-                if constexpr (FEAT & kFeatDrop) dpv = (((kp >> i) & 1u) ? dpv * p.keep_scale : 0.f) + nd;
-                pacc[i] = dead ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2) * dpv;
+                for (int i = 0; i < 16; ++i) {
+                    float dpv = pacc[i];
+                    if constexpr (FEAT & kFeatDrop) dpv = (((kp >> i) & 1u) ? dpv * p.keep_scale : 0.f) + nd;
+                    pacc[i] = __builtin_amdgcn_exp2f(sacc[i] * c_log2) * dpv;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    bool dead = rc_of(i) > thr;
+                    if constexpr (FEAT & kFeatMask) dead = dead || !((vis >> i) & 1u);
+                    float dpv = pacc[i];
+                    if constexpr (FEAT & kFeatDrop) dpv = (((kp >> i) & 1u) ? dpv * p.keep_scale : 0.f) + nd;
+                    pacc[i] = dead ? 0.f : __builtin_amdgcn_exp2f(sacc[i] * c_log2) * dpv;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -709,6 +760,7 @@ __global__ __launch_bounds__(512, 2) void exm_dq_kernel(const uint16_t* __restri
                     dqa[db] = mfma32<Tag>(a, sb, dqa[db]);
                 }
             }
+        }   // any_vis
         dma_wait_all();
         __syncthreads();
         cur ^= 1;

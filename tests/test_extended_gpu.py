@@ -136,6 +136,33 @@ def test_multi_tile_cases_on_both_kernel_families(bh, nq, nk, d, causal, mask_ki
     assert torch.equal(dq.cpu()[~live], torch.zeros_like(dq.cpu()[~live]))
 
 
+@pytest.mark.parametrize("nq,nk", [(700, 900), (512, 512), (900, 640)])
+def test_structured_dense_mask_takes_the_block_shortcuts_and_matches_the_causal_flag(nq, nk, device):
+    """look_ahead_mask handed over as bytes (what the notebook model does): most 32 x 32 blocks are all-visible or
+    all-masked and take the kernels' wave-uniform shortcuts (no per-byte work, no products for a block nobody sees); the
+    result must be the causal flag's within rounding."""
+    import flashattention_lab_cuda as ext
+    from common.attention_ex import look_ahead_mask
+
+    q, k, v, do, _, _ = _case(2, nq, nk, 128, torch.bfloat16, seed=5 + nq)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    mask = look_ahead_mask(nq, nk, device=device)[0, 0].to(torch.uint8).contiguous()
+    ext.set_option("ex_path", 3)
+    try:
+        o1, l1 = ext.ex_forward(qd, kd, vd, True, 0.09)
+        o2, l2 = ext.ex_forward(qd, kd, vd, False, 0.09, mask=mask)
+        g1 = ext.ex_backward(qd, kd, vd, o1, dod, l1, True, 0.09)
+        g2 = ext.ex_backward(qd, kd, vd, o2, dod, l2, False, 0.09, mask=mask)
+    finally:
+        ext.set_option("ex_path", 0)
+    # the same products in the same order; with ragged query tiles the lazy rescale of the online softmax fires on other
+    # tiles (rows past Nq are masked by the dense mask, visible to the flag's arithmetic), so the last bit may differ
+    assert max_abs(o1, o2) < 4e-3 and max_abs(l1[torch.isfinite(l1)], l2[torch.isfinite(l2)]) < 1e-4
+    assert torch.equal(torch.isfinite(l1), torch.isfinite(l2))
+    for a, b in zip(g1, g2):
+        assert max_abs(a, b) < 2e-2 * max(1.0, float(a.float().abs().max()))
+
+
 def test_mfma_family_refuses_what_it_does_not_cover(device):
     import flashattention_lab_cuda as ext
 

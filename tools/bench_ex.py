@@ -51,6 +51,7 @@ def main():
         "plain (Nq != Nk)": dict(),
         "causal, bottom-right aligned": dict(causal=True),
         "dense mask, half the pairs": dict(mask=dense),
+        "the causal mask handed over as a dense one": dict(mask=(kj <= qi + (nk - nq)).to(torch.uint8)),
         "block-sparse 128x128, a quarter of the tiles": dict(block_mask=bm, br=128, bc=128),
         "dropout 0.1": dict(dropout_p=0.1, seed=1),
         "causal + dropout 0.1": dict(causal=True, dropout_p=0.1, seed=1),
