@@ -442,6 +442,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
             __builtin_amdgcn_sched_barrier(0);
         };
         for_each_const(group, std::make_integer_sequence<int, 24>{});
+        // P^T(b + 1), rows 0 .. 31, is first read by the next iteration, behind mask_setup's branch: without a use in this
+        // basic block hipcc sinks the fma / exp2 that make it out of their gaps to the head of that iteration
+        asm volatile("" : "+v"(sacc[NXT][0]));
     };
 
     if (ntiles_w > 0) {
