@@ -105,11 +105,14 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
  *   mask             : Nq x Nk bytes, 0 = masked (masked_fill(mask == 0, -inf)); mask_bh_stride = 0 shares one mask over all
  *                      (b,h), Nq*Nk gives every (b,h) its own; NULL = none
  *   block_mask       : ceil(Nq/br) x ceil(Nk/bc) bytes, 0 = the tile is skipped (Algorithm 5 line 8); NULL = none
- *   dropout_p, seed  : standard dropout of the attention probabilities, keep where u > p, scale 1/(1-p); u comes from a
- *                      counter-based generator of (seed, b*h, i, j), so the backward regenerates the same mask; 0 = none
+ *   dropout_p, seed  : standard dropout of the attention probabilities, scale 1/(1-p); an element is kept where its 16
+ *                      uniform bits — a counter-based generator of (seed, b*h, i, j): one splitmix64 value per 2 x 2 quad of
+ *                      (row, key) elements — are >= floor(65536 p) + 1, so the backward regenerates the same mask; 0 = none
  *   softmax_scale    : includes the model's temperature tau
- * A query row with no visible key returns o = 0, lse = -inf (the reference's softmax of an all -inf row is NaN).
- * Exact-f32 kernels (every dtype, d <= 256). */
+ * A query row with no visible key returns o = 0, lse = -inf, dq = 0 (the reference's softmax of an all -inf row is NaN).
+ * Kernels: f16 / bf16 tensors with d % 8 == 0, d <= 128, softmax_scale > 0 and block-mask blocks that are multiples of 32 run
+ * on 16-bit MFMA kernels (a square call without any extra is the plain fa2 path); everything else — f32, d <= 256 — on exact-f32
+ * kernels.  Same results contract either way. */
 int fa_ex_forward(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype,
                   int causal, double softmax_scale,
