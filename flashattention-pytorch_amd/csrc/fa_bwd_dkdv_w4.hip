@@ -83,6 +83,18 @@ template <int OFF> __device__ __forceinline__ void lds_acc_init(unsigned addr, f
     }
 }
 
+// The same from inline asm, for the loads inside the stream: the four reads land in the four quarters of the accumulator tuple
+// (joined by shufflevectors: no copies), hipcc knows of no load and places no wait — its wait would drain the operand requests
+// in flight — and the stream's counted waits cover them (38.7 -> 38.1 cycles per MFMA).
+template <int OFF> __device__ __forceinline__ void lds_acc_init_asm(unsigned addr, f32x16& acc) {
+    typedef float f32x8_t __attribute__((ext_vector_type(8)));
+    f32x4 t0, t1, t2, t3;
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(addr), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96));
+    const f32x8_t lo = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(t2, t3, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+
 // ABL != 0: profiling ablations (wrong results on purpose; option dkdv_abl):
 //   bit 0: no vector slices (P, dS)   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no LDS operand requests
 //   bit 3: no row-constant loads      bit 4: no address updates
@@ -104,10 +116,9 @@ __device__ __forceinline__ void dma4_issue_s(rsrc_s_t rsrc, unsigned lds_dst, in
 // tools/gen_dkdv_schedule.py from the gap budgets: an MFMA leaves the wave about 24 cycles of issue, the operand
 // requests in front of every even MFMA take 8 .. 16 of them.  MUL / EXP: one element of S' -> P; PC: a packed dword of P;
 // SU: a packed dword of dS; ACC: row constants -> an initial accumulator of the next block; DMA: an LDS-DMA piece of the
-// tile three blocks ahead; QADDR / TADDR / LADDR: operand addresses to the next tile's buffer; USE: where hipcc waits
-// for the ACC loads.
+// tile three blocks ahead; QADDR / TADDR / LADDR: operand addresses to the next tile's buffer.
 namespace w4sched {
-enum : unsigned char { NONE = 0, OP_MUL, OP_EXP, OP_PC, OP_SU, OP_ACC, OP_LADDR, OP_USE, OP_DMA, OP_QADDR, OP_TADDR };
+enum : unsigned char { NONE = 0, OP_MUL, OP_EXP, OP_PC, OP_SU, OP_ACC, OP_LADDR, OP_DMA, OP_QADDR, OP_TADDR };
 struct Op { unsigned char op, a, b; };
 constexpr Op MUL(int kb, int e) { return {OP_MUL, (unsigned char)kb, (unsigned char)e}; }
 constexpr Op EXP(int kb, int e) { return {OP_EXP, (unsigned char)kb, (unsigned char)e}; }
@@ -117,7 +128,7 @@ constexpr Op ACC(int w) { return {OP_ACC, (unsigned char)w, 0}; }
 constexpr Op DMA(int j) { return {OP_DMA, (unsigned char)j, 0}; }
 constexpr Op QADDR(int i) { return {OP_QADDR, (unsigned char)i, 0}; }
 constexpr Op TADDR(int j) { return {OP_TADDR, (unsigned char)j, 0}; }
-constexpr Op LADDR{OP_LADDR, 0, 0}, USE{OP_USE, 0, 0};
+constexpr Op LADDR{OP_LADDR, 0, 0};
 constexpr int kWidth = 5;
 // generated by tools/gen_dkdv_schedule.py: 0 cycles over budget in 0 gaps
 // slice S (after MFMA S): up to 5 operations
@@ -184,7 +195,7 @@ constexpr Op kSched[64][kWidth] = {
     /* 59 ( 8) */ {TADDR(3)},
     /* 60 (24) */ {},
     /* 61 ( 8) */ {},
-    /* 62 (24) */ {USE},
+    /* 62 (24) */ {},
     /* 63 ( 8) */ {},
 };
 }  // namespace w4sched
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         const int qs = qs_first + BQ * blk;
         const bool need_mask = (CAUSAL && (kw0 + 63 > qs)) || (kw0 + 64 > n);   // wave-uniform
         if (need_mask) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sacc[0]), "+v"(sacc[1]));   // the row constants were read from asm: hipcc places no wait
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int key = kw0 + 32 * kb + r;
@@ -343,10 +355,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                     else if constexpr (o.op == w4sched::OP_PC && !(ABL & 1)) PC(integral_constant<int, a>{}, integral_constant<int, b>{});
                     else if constexpr (o.op == w4sched::OP_SU && !(ABL & 1)) SU(integral_constant<int, a>{}, integral_constant<int, b>{});
                     else if constexpr (o.op == w4sched::OP_ACC && !(ABL & 8)) {
-                        if constexpr (a < 2) lds_acc_init<0>(laddr, sacc[a]);
-                        else lds_acc_init<256>(laddr, pacc[a - 2]);
+                        if constexpr (a < 2) lds_acc_init_asm<0>(laddr, sacc[a]);
+                        else lds_acc_init_asm<256>(laddr, pacc[a - 2]);
                     }
-                    else if constexpr (o.op == w4sched::OP_USE && !(ABL & 8)) asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(pacc[0]), "+v"(pacc[1]));
                     else if constexpr (o.op == w4sched::OP_DMA && !(ABL & 2)) dma_piece(integral_constant<int, a>{}, blk + 3);
                     else if constexpr (o.op == w4sched::OP_LADDR && !(ABL & 16)) laddr += dlt;
                     else if constexpr (o.op == w4sched::OP_QADDR && !(ABL & 16)) qaddr[a] += dlt;
@@ -360,7 +371,16 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             // a lead of two groups for those), an odd group issues no wait — one instruction less per four MFMAs (39.3 -> 38.7
             // cycles per MFMA)
             constexpr bool WAITS = (g % 2) == 0;
-            constexpr int NWAIT = G::reads(g + 2) + G::reads(g + 3);
+            // (the row-constant reads issued since group g + 1 was requested — in the slices behind MFMAs 2 g - 4 .. 2 g - 1 — are
+            // in the queue too)
+            constexpr int ACCS = [] {
+                int c = 0;
+                for (int S = 2 * g - 4; S <= 2 * g - 1; ++S)
+                    for (int j = 0; j < w4sched::kWidth; ++j)
+                        if (w4sched::kSched[(S + 64) % 64][j].op == w4sched::OP_ACC) c += 4;
+                return c;
+            }();
+            constexpr int NWAIT = G::reads(g + 2) + G::reads(g + 3) + ((ABL & 8) ? 0 : ACCS);
             using M = W4Stream<Tag, WAITS>;
             constexpr int g2 = (g + AHEAD) % 32, ph2 = g2 / 8, i2 = g2 % 8, t0 = G::slot(g2);   // the group requested here
             // first operand of the MFMAs, second operand / accumulator of key block 0 and 1

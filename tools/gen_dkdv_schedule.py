@@ -9,10 +9,10 @@ take their share of that gap; what is left is the budget the block's other work 
     MUL / EXP   one element of S' -> P = exp2(c S')             (kb, element): after the S' chain, before the dV products
     PC          one packed dword of P                           (kb, pair)
     SU          one packed dword of dS = P dP'                  (kb, pair): after the dP' chain, before the dK products
-    ACC         row constants -> initial accumulator (4 LDS reads), once the accumulator's last reader is behind
+    ACC         row constants -> initial accumulator (4 LDS reads from asm: the stream's counted waits cover them), once the
+                accumulator's last reader is behind
     DMA         one LDS-DMA piece of the tile three blocks ahead
     QADDR / TADDR / LADDR   operand addresses moved to the next tile's buffer, after their last use in this block
-    USE         the place where hipcc waits for the ACC loads
 
 A gap that is over its budget stretches by the excess (tools/asm_gaps.py measures a built kernel the same way).  This
 script packs the work greedily, earliest deadline first, and prints the table as C++.
@@ -67,7 +67,6 @@ def main():
         add(f"ACC({kb})", 16, 40, 61, before=sus + ("LADDR",))        # S'[kb]
         add(f"ACC({2 + kb})", 16, 40, 61, before=sus + ("LADDR",))    # dP'[kb]
     add("LADDR", 4, 1, 60)                       # the row constants of this block were read before its first MFMA
-    add("USE", 0, 62, 63, before=tuple(f"ACC({i})" for i in range(4)))
     for j in range(5):
         add(f"DMA({j})", 16, 0, 40)              # the target buffer was last read in the previous block
     for i in range(8):
