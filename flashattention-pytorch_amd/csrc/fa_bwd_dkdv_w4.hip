@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                                                              const float* __restrict__ nlse,
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
                                                              uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
-                                                             float scale) {
+                                                             float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */) {
     constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = 16;
     // operand groups requested ahead of use (6 MFMAs).  4 live groups x 3 fragments = 12 ring slots; with 16 a request
     // never lands on a fragment the two MFMAs just issued are still reading (hipcc would pad that hazard with an s_nop)
@@ -233,17 +233,18 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     };
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * D, kvbase = (size_t)bh * nk * D;   // q / dO rows; k / v / dk / dv rows
     const size_t rbase = (size_t)bh * n;
+    const int coff = nk - n;
     int key0 = 0, kw0 = 0;                       // first key of the current tile / of this wave in it
 
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + kvbase, (unsigned)nk * D * 2);
     const rsrc_s_t q_rs = make_rsrc_s(q + base, (unsigned)n * D * 2);
     const rsrc_s_t o_rs = make_rsrc_s(dout + base, (unsigned)n * D * 2);
     const rsrc_s_t l_rs = make_rsrc_s(nlse + rbase, (unsigned)n * 4);
     const rsrc_s_t d_rs = make_rsrc_s(ndelta + rbase, (unsigned)n * 4);
     const rsrc_s_t lr_rs = (w & 1) ? d_rs : l_rs;   // this wave's row-constant source (wave-uniform select)
-    const buf_rsrc_t v_rs = make_rsrc(v + base, (unsigned)n * D * 2);
+    const buf_rsrc_t v_rs = make_rsrc(v + kvbase, (unsigned)nk * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, D);
 
     int qs_first = 0, nblk = 0;                  // first query of the current tile's sweep, 32-query blocks in it
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     unsigned kaddr[NKS], qaddr[NKS], tlo[NDB], thi[NDB], laddr;
     // first block this wave computes: earlier ones hold only queries before its first key (causal)
-    const int fb = CAUSAL ? 2 * w : 0;
+    int fb = 0;
     unsigned stamp_cycles = 0;
     // ---- the stream.  Operand groups g = 0 .. 31 of a block, two MFMAs each (key block 0, then 1):
     //   g =  0 ..  7  S'[kb]  += Q[ks] K[kb][ks]          reads: Q rows, K rows of block 0, K rows of block 1
@@ -311,13 +312,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // when it precedes this lane's key (causal) or the key lies past n: rc(i) < thr, one per-lane threshold per key block.
     auto mask_init = [&](int blk) {   // blk: the block whose initial accumulators were just requested
         const int qs = qs_first + BQ * blk;
-        const bool need_mask = (CAUSAL && (kw0 + 63 > qs)) || (kw0 + 64 > n);   // wave-uniform
+        const bool need_mask = (CAUSAL && (kw0 + 63 - coff > qs)) || (kw0 + 64 > nk);   // wave-uniform
         if (need_mask) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sacc[0]), "+v"(sacc[1]));   // the row constants were read from asm: hipcc places no wait
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int key = kw0 + 32 * kb + r;
-                const int thr = key >= n ? 64 : (CAUSAL ? key - qs - 4 * h : -1);
+                const int thr = key >= nk ? 64 : (CAUSAL ? key - coff - qs - 4 * h : -1);
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if ((i & 3) + 8 * (i >> 2) < thr) sacc[kb][i] = -1e30f;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     if (TPW > 1 && kt < 0) break;
     key0 = kt * BK;
     kw0 = key0 + 64 * w;
-    qs_first = CAUSAL ? key0 : 0;                // earlier queries see none of this tile's keys
+    qs_first = CAUSAL ? (max(0, key0 - coff) / BQ) * BQ : 0;   // earlier queries see none of this tile's keys
+    fb = CAUSAL ? (max(0, kw0 - coff) - qs_first) / BQ : 0;    // (nq == nk: 2 w)
     nblk = (n - qs_first + BQ - 1) / BQ;
     // ---- prologue of a key tile: K tile, V fragments (B operand of dP = dO V^T), query tiles 0 .. 2
     dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, dma_voff, w);
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                 vals[4 * db + g][0] = pack2_rn<Tag>(dka[kb][db][4 * g + 0] * scale, dka[kb][db][4 * g + 1] * scale);
                 vals[4 * db + g][1] = pack2_rn<Tag>(dka[kb][db][4 * g + 2] * scale, dka[kb][db][4 * g + 3] * scale);
             }
-        store_rows_via_lds<D>(stg, vals, dk + base, kw0 + 32 * kb, n, lane, D);
+        store_rows_via_lds<D>(stg, vals, dk + kvbase, kw0 + 32 * kb, nk, lane, D);
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                 vals[4 * db + g][0] = pack2_rn<Tag>(dva[kb][db][4 * g + 0], dva[kb][db][4 * g + 1]);
                 vals[4 * db + g][1] = pack2_rn<Tag>(dva[kb][db][4 * g + 2], dva[kb][db][4 * g + 3]);
             }
-        store_rows_via_lds<D>(stg + 32 * D * 2, vals, dv + base, kw0 + 32 * kb, n, lane, D);
+        store_rows_via_lds<D>(stg + 32 * D * 2, vals, dv + kvbase, kw0 + 32 * kb, nk, lane, D);
     }
     if (TPW > 1) __syncthreads();   // the K tile and the query-tile buffers are about to be refilled
     }   // key tiles of this workgroup
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
 template <typename Tag>
 static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     constexpr int D = 128, BK = 256;
-    const int nkt = (int)((a.n + BK - 1) / BK);
+    const int64_t nk = a.nk > 0 ? a.nk : a.n;
+    const int nkt = (int)((nk + BK - 1) / BK);
     const size_t smem = (size_t)BK * D * 2 + 4 * (2 * 32 * D * 2 + 1024);
     const float c = a.scale * 1.4426950408889634f;
     // key tiles per workgroup: 2 under the causal mask (heavy + light pair), else 1
@@ -561,7 +564,7 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k, (const uint16_t*)a.v,
-                           (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale);
+                           (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale, (int)nk);
         return hipGetLastError();
     };
     if constexpr (std::is_same<Tag, bf16_tag>::value) {

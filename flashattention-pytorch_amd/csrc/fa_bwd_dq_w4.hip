@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ o, const float* __restrict__ lse,
                                                            float* __restrict__ nlse, float* __restrict__ ndelta,
                                                            uint16_t* __restrict__ dq, int n, int nqt, float c_log2,
-                                                           float scale) {
+                                                           float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */) {
     constexpr int D = 128, NKS = 8, NDB = 4, BM = 256, BN = 64, NBUF = 4, RS = 8, AHEAD = 3;
     constexpr int KT = BN * D * 2;               // 16 KiB: the K rows of a tile (the V rows follow)
     constexpr int BUF = 2 * KT;                  // K | V
@@ -208,13 +208,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
         if (CAUSAL ? (i == 0 || grp < nqt - 1 - grp) : (tile_of(i) < nqt)) ntile_wg = i + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const size_t base = (size_t)bh * n * D;
+    const size_t base = (size_t)bh * n * D, kbase = (size_t)bh * nk * D;
+    const int coff = nk - n;
 
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * D * 2);
     const buf_rsrc_t o_rs = make_rsrc(dout + base, (unsigned)n * D * 2);
     const buf_rsrc_t y_rs = make_rsrc(o + base, (unsigned)n * D * 2);   // the forward's output
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * D * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * D * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + kbase, (unsigned)nk * D * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + kbase, (unsigned)nk * D * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, D);
     const unsigned bbase = lds_addr_of(smem);
 
@@ -253,12 +254,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
     // otherwise.
     bool mt_dirty = false;
     auto mask_setup = [&](int q0w, int k0) {   // q0w: first row of the wave, k0: first key of the block
-        const bool need_mask = (CAUSAL && (k0 + 31 > q0w)) || (k0 + 32 > n);   // wave-uniform
+        const bool need_mask = (CAUSAL && (k0 + 31 > q0w + coff)) || (k0 + 32 > nk);   // wave-uniform
         if (need_mask) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int qrow = q0w + 32 * qb + r;
-                const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;   // last visible key of this lane's row
+                const int lim = CAUSAL ? min(qrow + coff, nk - 1) : nk - 1;   // last visible key of this lane's row
                 const int thr = lim - (k0 + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mt[qb][i] = ((i & 3) + 8 * (i >> 2) > thr) ? -1e30f : 0.f;
@@ -276,10 +277,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
     for (int it = 0; it < ntile_wg; ++it) {
     const int q0 = tile_of(it) * BM;
     const int q0w = q0 + 64 * w;
-    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int kend = CAUSAL ? min(nk, q0 + BM + coff) : nk;
     const int ntiles = (kend + BN - 1) / BN;
     // tiles this wave computes: under the causal mask a tile whose first key lies past the wave's last row is skipped
-    const int ntiles_w = CAUSAL ? min(ntiles, (q0w + 63) / BN + 1) : ntiles;
+    const int ntiles_w = CAUSAL ? min(ntiles, (q0w + 63 + coff) / BN + 1) : ntiles;
 
     // ---- prologue of a query tile: Q, dO fragments; row constants (made here and stored for the dK/dV kernel:
     // -delta = -rowsum(dO * O), csrc/fa2/fa2_bwd.cu:57, from this lane's half of the row plus lane ^ 32's; -lse / scale)
@@ -546,7 +547,7 @@ static hipError_t launch_dq_w4_t(const BwdArgs& a, float* nlse, float* ndelta, h
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k, (const uint16_t*)a.v,
                            (const uint16_t*)a.dout, (const uint16_t*)a.o, a.lse, nlse, ndelta, (uint16_t*)a.dq, (int)a.n, nqt, c,
-                           a.scale);
+                           a.scale, (int)(a.nk > 0 ? a.nk : a.n));
         return hipGetLastError();
     };
     if constexpr (std::is_same<Tag, bf16_tag>::value) {

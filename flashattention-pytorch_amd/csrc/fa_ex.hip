@@ -373,11 +373,28 @@ hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
     const int path = option(OPT_EX_PATH);   // 0: MFMA kernels where they apply, 1: always these, 2: MFMA or fail, 3: MFMA, never the plain kernels
     // no extras at all on a square problem: this IS the plain path — hand it to the tuned kernels (same results contract;
     // the workspace of fa_ex_backward_workspace_bytes covers their row constants)
-    if ((path == 0 || path == 2) && a.nq == a.nk && !a.mask && !a.block_mask && a.dropout_p <= 0.0 && a.scale > 0.f &&
-        (backward ? bwd_mfma_supported(a.dtype, a.d) : fwd_mfma_supported(a.dtype, a.d))) {
+    const bool plain = (path == 0 || path == 2) && !a.mask && !a.block_mask && a.dropout_p <= 0.0 && a.scale > 0.f;
+    if (plain && a.nq == a.nk && (backward ? bwd_mfma_supported(a.dtype, a.d) : fwd_mfma_supported(a.dtype, a.d))) {
         if (!backward) return launch_fwd_mfma(FwdArgs{a.q, a.k, a.v, a.o, a.lse, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale}, st);
         return launch_bwd_mfma(BwdArgs{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale,
                                        a.workspace, ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
+    }
+    // Nq != Nk without masks or dropout (cross attention; a cached prefix under the causal mask): the d = 128 kernels of the plain
+    // path take separate row counts.  Under the causal mask only with Nk >= Nq: they assume that every query row sees key 0.
+    if (plain && a.nq != a.nk && nqnk_mfma_supported(a.dtype, a.d, a.bh, a.nq, a.nk, a.causal)) {
+        if (!backward) {
+            FwdArgs f{a.q, a.k, a.v, a.o, a.lse, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale};
+            f.nk = a.nk;
+            return launch_fwd_nqnk(f, st);
+        }
+        BwdArgs b{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale, a.workspace,
+                  ex_backward_workspace_bytes(a.bh, a.nq), 0};
+        b.nk = a.nk;
+        float* nlse = reinterpret_cast<float*>(a.workspace);
+        float* ndelta = nlse + (size_t)a.bh * a.nq;
+        hipError_t e = launch_bwd_dq_w4(b, nlse, ndelta, st);   // makes the row constants on its way
+        if (e != hipSuccess) return e;
+        return launch_bwd_dkdv_w4(b, nlse, ndelta, st);
     }
     if (path != 1 && ex_mfma_supported(a)) return launch_ex_mfma(a, backward, st);
     if (path >= 2) return hipErrorInvalidConfiguration;

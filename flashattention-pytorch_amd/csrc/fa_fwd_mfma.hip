@@ -359,7 +359,8 @@ template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
-                                                               float scale, int dr_dbg /* row length | debug ablation flags (option fwd_abl) << 16 */) {
+                                                               float scale, int dr_dbg /* row length | debug ablation flags (option fwd_abl) << 16 */,
+                                                               int nk /* keys; n = query rows; causal needs nk >= n: the diagonal sits at key = row + nk - n */) {
     const int dbg = dr_dbg >> 16;
     const int DR = PAD ? (dr_dbg & 0xffff) : D;   // elements per tensor row (PAD: head dims below the tile width, fa_common.h)
     constexpr int BM = 256, BN = 32 * KB, NKS = D / 16, NDV = D / 32;
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int qrow = q0 + 32 * w + r;
-    const size_t base = (size_t)bh * n * DR;
+    const size_t base = (size_t)bh * n * DR, kbase = (size_t)bh * nk * DR;
+    const int coff = nk - n;
     const int stag = w >> 2;   // waves 4..7 (the second wave of every SIMD) run one half-step behind
 
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
@@ -387,12 +389,12 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = buf_load_frag(q_rs, frag_off(qrow, 16 * ks + 8 * h, DR, PAD));
 
-    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int kend = CAUSAL ? min(nk, q0 + BM + coff) : nk;
     const int T = (kend + BN - 1) / BN;                                               // tiles of the workgroup
-    const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31) / BN + 1) : T;                  // tiles this wave computes
+    const int Tw = CAUSAL ? min(T, (q0 + 32 * w + 31 + coff) / BN + 1) : T;                  // tiles this wave computes
 
-    const rsrc_s_t k_rs = make_rsrc_s(k + base, (unsigned)n * DR * 2);
-    const rsrc_s_t v_rs = make_rsrc_s(v + base, (unsigned)n * DR * 2);
+    const rsrc_s_t k_rs = make_rsrc_s(k + kbase, (unsigned)nk * DR * 2);
+    const rsrc_s_t v_rs = make_rsrc_s(v + kbase, (unsigned)nk * DR * 2);
     const int dma_voff = dma_lane_voff<D>(lane, w, DR);
     // Issued at the start of global half-step 2u, first read in half-step 2u+4: K(u+2) and V(u+1).  Two tiles of
     // flight time (a 64-key tile is consumed in about a microsecond, less than one trip to L2 / HBM under load).
@@ -447,9 +449,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             return;
         }
         const int k0 = t * BN;
-        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w + coff)) || (k0 + BN > nk);
         if (need_mask) {
-            const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+            const int lim = CAUSAL ? min(qrow + coff, nk - 1) : nk - 1;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int thr = lim - (k0 + 32 * kb + 4 * h);
@@ -680,7 +682,14 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
         if (want_stag) {
             smem = (size_t)2 * (KB == 4 ? 2 : 3) * (32 * KB) * D * 2;
             last_arg = (int)a.d | ((option(OPT_FWD_STAG) != 0 ? option(OPT_FWD_ABL) : 0) << 16);   // debug flags only with an explicit fwd_stag
-            return a.causal ? launch(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD>) : launch(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD>);
+            auto launch_s = [&](auto kern) -> hipError_t {
+                hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k,
+                                   (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, last_arg, (int)(a.nk > 0 ? a.nk : a.n));
+                return hipGetLastError();
+            };
+            return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD>);
         }
     }
     if constexpr (!PAD && D != 256) {   // sweep variants exist for the 64 / 128 tile widths only
@@ -765,6 +774,13 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
     return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key (LDS 128 KiB at d = 128)
+}
+
+bool nqnk_mfma_supported(int dtype, int64_t d, int64_t bh, int64_t nq, int64_t nk, int causal) {
+    return (dtype == 1 || dtype == 2) && d == 128 && nq > 0 && nk > 0 && (!causal || nk >= nq) && !small_grid(bh, nq < nk ? nq : nk);
+}
+hipError_t launch_fwd_nqnk(const FwdArgs& a, hipStream_t st) {   // the staggered kernel, 128-key tiles, with a.nk keys
+    return a.dtype == 2 ? launch_fwd_t<bf16_tag, 128, 4>(a, st, true) : launch_fwd_t<f16_tag, 128, 4>(a, st, true);
 }
 
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {

@@ -14,6 +14,7 @@ struct FwdArgs {
     int dtype;  // FA_DTYPE_*
     int causal;
     float scale;
+    int64_t nk = 0;   // keys (0: = n, the query rows).  Only the kernels fwd_nqnk_supported() names take nk != n.
 };
 
 struct BwdArgs {
@@ -27,6 +28,7 @@ struct BwdArgs {
     void* workspace;
     size_t workspace_bytes;
     int fused_dq;  // 1: single kernel, dQ by global float atomics; 0: dK/dV kernel + dQ kernel (deterministic)
+    int64_t nk = 0;   // keys (0: = n, the query rows).  Only the stream kernels take nk != n (causal: nk >= n).
 };
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
@@ -62,6 +64,10 @@ bool fwd_mfma_supported(int dtype, int64_t d);
 bool small_grid(int64_t bh, int64_t n);   // 256-row tiling would leave CUs idle: use the 4-wave / 128-row kernels
 hipError_t set_trace_buffer(void* device_ptr);   // debug: phase timestamps of the staggered forward (fa_fwd_mfma.hip)
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st);
+// Nq != Nk on the plain path's d = 128 kernels (staggered forward, stream backward): 16-bit tensors, Nk % 64 == 0 not needed,
+// causal only with Nk >= Nq, launches big enough for the 256-row tiles
+bool nqnk_mfma_supported(int dtype, int64_t d, int64_t bh, int64_t nq, int64_t nk, int causal);
+hipError_t launch_fwd_nqnk(const FwdArgs& a, hipStream_t st);
 bool bwd_mfma_supported(int dtype, int64_t d);
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant);   // fp32 dQ scratch only for the single-kernel variant

@@ -111,7 +111,8 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
  *   softmax_scale    : includes the model's temperature tau
  * A query row with no visible key returns o = 0, lse = -inf, dq = 0 (the reference's softmax of an all -inf row is NaN).
  * Kernels: f16 / bf16 tensors with d % 8 == 0, d <= 128, softmax_scale > 0 and block-mask blocks that are multiples of 32 run
- * on 16-bit MFMA kernels (a square call without any extra is the plain fa2 path); everything else — f32, d <= 256 — on exact-f32
+ * on 16-bit MFMA kernels (a call without mask and dropout takes the plain fa2 kernels: square as it is; Nq != Nk at d = 128,
+ * causal only with Nk >= Nq); everything else — f32, d <= 256 — on exact-f32
  * kernels.  Same results contract either way. */
 int fa_ex_forward(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype,

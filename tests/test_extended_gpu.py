@@ -163,6 +163,44 @@ def test_structured_dense_mask_takes_the_block_shortcuts_and_matches_the_causal_
         assert max_abs(a, b) < 2e-2 * max(1.0, float(a.float().abs().max()))
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("nq,nk", [(1024, 1536), (1000, 1300), (1536, 1024)])
+def test_big_launches_without_extras_take_the_plain_kernels_with_separate_row_counts(nq, nk, causal, device):
+    """Nq != Nk, no mask, no dropout, d = 128, a launch big enough for the 256-row tiles: the staggered forward and the stream
+    backward of the plain path run with nk keys (causal only with Nk >= Nq; otherwise the extended kernels).  Checked against
+    the extended MFMA kernels on every unit and against the fp64 oracle on two."""
+    import flashattention_lab_cuda as ext
+
+    bh, d = 64, 128
+    g = torch.Generator().manual_seed(nq + nk)
+    q = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16)
+    k = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16)
+    v = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16)
+    do = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    scale = d ** -0.5
+    o, lse = ext.ex_forward(qd, kd, vd, causal, scale)
+    grads = ext.ex_backward(qd, kd, vd, o, dod, lse, causal, scale)
+    ext.set_option("ex_path", 3)
+    try:
+        o3, lse3 = ext.ex_forward(qd, kd, vd, causal, scale)
+        grads3 = ext.ex_backward(qd, kd, vd, o3, dod, lse3, causal, scale)
+    finally:
+        ext.set_option("ex_path", 0)
+    live = torch.isfinite(lse3)
+    assert torch.equal(torch.isfinite(lse), live)
+    assert max_abs(o, o3) < 8e-3 and max_abs(lse[live], lse3[live]) < 1e-3
+    for a, b in zip(grads, grads3):
+        assert torch.isfinite(a.float()).all() and max_abs(a, b) < 3e-2 * max(1.0, float(b.float().abs().max()))
+    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q[:2], k[:2], v[:2], do[:2], causal=causal, softmax_scale=scale)
+    tol = dtype_tolerances(torch.bfloat16)
+    torch.testing.assert_close(o[:2].cpu(), ro, **tol)
+    lv = torch.isfinite(rlse)
+    torch.testing.assert_close(lse[:2].cpu()[lv], rlse[lv], rtol=1e-3, atol=1e-3)
+    for a, b in zip(grads, (rq, rk, rv)):
+        torch.testing.assert_close(a[:2].cpu(), b, **tol)
+
+
 def test_mfma_family_refuses_what_it_does_not_cover(device):
     import flashattention_lab_cuda as ext
 

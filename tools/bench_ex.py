@@ -2,7 +2,7 @@
 family (16-bit MFMA kernels, csrc/fa_ex_mfma.hip; exact-f32 kernels, csrc/fa_ex.hip), with the visible fraction of the
 score matrix accounted for (algorithmic FLOPs = 4 / 10 x visible (q, key) pairs x d).
 
-    python tools/bench_ex.py [--bh 32] [--nq 2048] [--nk 4096] [--head-dim 128] [--dtype bf16] [--paths mfma,exact]
+    python tools/bench_ex.py [--bh 32] [--nq 2048] [--nk 4096] [--head-dim 128] [--dtype bf16] [--paths default,mfma,exact]
 """
 import argparse
 import json
@@ -59,7 +59,7 @@ def main():
     rows = []
     paths = ["exact"] if args.dtype == "fp32" else args.paths.split(",")
     for path in paths:
-      ext.set_option("ex_path", 3 if path == "mfma" else 1)   # 3: the extended MFMA kernels even where the plain ones would do
+      ext.set_option("ex_path", {"mfma": 3, "exact": 1}.get(path, 0))   # 3: the extended MFMA kernels even where the plain ones would do; default: the library's own choice
       for name, kw in cases.items():
         kw = dict(kw)
         causal = kw.pop("causal", False)
