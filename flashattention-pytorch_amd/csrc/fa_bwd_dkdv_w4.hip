@@ -200,14 +200,22 @@ constexpr Op kSched[64][kWidth] = {
 };
 }  // namespace w4sched
 
-template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1)>
+// DS: the variant that hands dS to the dQ product kernel (fa_bwd_dq_ds.hip) instead of leaving dQ to a pass that recomputes S
+// and dP.  The packed dS of a block — already the B operand of the dK^T products, 4 x 16 bytes per lane — is stored as it
+// is: tile (b,h; 32-query block qb; 32-key block kb) of 2 KiB at ds + (((b,h) nqb + qb) nkb32 + kb) 2048 bytes, inside it
+// [16-query half s][key r][h][8 queries]: every store instruction writes 1 KiB contiguous, a wave 4 KiB per block, the
+// workgroup 16 KiB.  Element j of lane (r, h) is query 16 s + 8 (j >> 2) + 4 h + (j & 3) of the block (the accumulator's
+// register order); fa_bwd_dq_ds.hip reads the tiles back transposed (ds_read_b64_tr_b16).  Blocks the causal mask removes
+// whole (queries before the wave's first key) are never written; masked elements of the others are written as 0.
+template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1), bool DS = false>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ nlse,
                                                              const float* __restrict__ ndelta, uint16_t* __restrict__ dk,
                                                              uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
-                                                             float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */) {
+                                                             float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */,
+                                                             uint16_t* __restrict__ ds = nullptr, int nqb = 0, int nkb32 = 0 /* DS: tile grid of the dS workspace */) {
     constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = 16;
     // operand groups requested ahead of use (6 MFMAs).  4 live groups x 3 fragments = 12 ring slots; with 16 a request
     // never lands on a fragment the two MFMAs just issued are still reading (hipcc would pad that hazard with an s_nop)
@@ -266,8 +274,19 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         }
     };
     auto stage = [&](int t) { for_each_const([&](auto jc) { dma_piece(jc, t); }, std::make_integer_sequence<int, 5>{}); };
-    // all but this wave's newest tile (4 pieces + 1 row-constant piece) have landed
-    auto wait_tiles = [&]() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); };
+    // all but this wave's newest tile (4 pieces + 1 row-constant piece) have landed.  DS: the block's four dS stores were
+    // issued behind those pieces and count too (vector-memory operations of all kinds retire in issue order); from the
+    // stream's second block on the previous block's stores may still be in flight as well: they have a block to complete.
+    // What the stores cost is their issue — 44 cycles each, 7 % of the block, wherever they sit in it (stores into a
+    // private, L2-resident tile cost the same as the real ones; not waiting for them saves nothing: ds_st ablations of
+    // profiles/r02_ds_handover.md).
+    auto wait_tiles = [&](bool first_block = false) {
+        if (!DS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (first_block) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    };
+    const int ds_voff = 32 * (lane & 31) + 16 * (lane >> 5);
+    unsigned long long dsp = 0;                  // DS: this wave's two dS tiles of the current block (wave-uniform address)
 
     s16x8 vf[2][NKS];
     f32x16 dka[2][NDB], dva[2][NDB];
@@ -345,8 +364,19 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         // consumer sits at least two MFMAs behind the chain it reads (hipcc pads nothing around the asm MFMAs;
         // tools/mfma_hazard_audit.py checks the built code) — and every gap within its issue budget: 42.1 -> 39.3 cycles per
         // MFMA against the first hand placement, bitwise the same results (profiles/r02_cycles_dkdv.md).
+        // DS: the four stores of the block's packed dS, in the gaps behind the last SU (tools/gen_dkdv_schedule.py --ds
+        // places them there and moves nothing else: DSST(0,0) 52, DSST(0,1) 53, DSST(1,0) 54, DSST(1,1) 55)
+        auto DSST = [&](auto kbc, auto hc) {
+            constexpr int kb = decltype(kbc)::value, half = decltype(hc)::value;
+            const int vo = ds_voff;                 // (locals: hipcc does not capture a variable that only an asm operand names)
+            const unsigned long long p = dsp;
+            const u32x4 x = sp[kb][half];
+            // nt: the tiles are read once, by another kernel (nt / sc1 / plain: 3.476 / 3.466 / 3.506 ms)
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" :: "v"(vo), "v"(x), "s"(p), "n"(2048 * kb + 1024 * half));
+        };
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
+            if constexpr (DS && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});
             {   // ABL bits: see the kernel's header comment
                 for_each_const([&](auto jc) {
                     constexpr w4sched::Op o = w4sched::kSched[S][decltype(jc)::value];
@@ -430,6 +460,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     qs_first = CAUSAL ? (max(0, key0 - coff) / BQ) * BQ : 0;   // earlier queries see none of this tile's keys
     fb = CAUSAL ? (max(0, kw0 - coff) - qs_first) / BQ : 0;    // (nq == nk: 2 w)
     nblk = (n - qs_first + BQ - 1) / BQ;
+    if (DS) dsp = (unsigned long long)(uintptr_t)ds + (((unsigned long long)bh * nqb + qs_first / BQ + fb) * nkb32 + (kw0 >> 5)) * 2048ull;
     // ---- prologue of a key tile: K tile, V fragments (B operand of dP = dO V^T), query tiles 0 .. 2
     dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, dma_voff, w);
 #pragma unroll
@@ -477,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // feed-only blocks (causal: queries before this wave's first key): the wave's share of the LDS-DMA and the barriers
     for (int blk = 0; blk < min(fb, nblk); ++blk) {
         stage(blk + 3);
-        wait_tiles();
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // (no stores here: the count of the plain kernel)
         __builtin_amdgcn_s_barrier();
     }
     if (fb < nblk) {
@@ -498,8 +529,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         for (int blk = fb; blk < nblk; ++blk) {
             block(blk);
             mask_init(blk + 1);   // on the next block's initial accumulators, outside the stream (the only branch)
+            if (DS) dsp += (unsigned long long)nkb32 * 2048;
             if (!(ABL & 2)) {
-                wait_tiles();
+                wait_tiles(blk == fb);
                 __builtin_amdgcn_s_barrier();
             }
         }
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
 }
 
 template <typename Tag>
-static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
+static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st, void* ds) {
     constexpr int D = 128, BK = 256;
     const int64_t nk = a.nk > 0 ? a.nk : a.n;
     const int nkt = (int)((nk + BK - 1) / BK);
@@ -564,9 +596,11 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.q, (const uint16_t*)a.k, (const uint16_t*)a.v,
-                           (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale, (int)nk);
+                           (const uint16_t*)a.dout, nlse, ndelta, (uint16_t*)a.dk, (uint16_t*)a.dv, (int)a.n, nkt, c, a.scale, (int)nk,
+                           (uint16_t*)ds, ds_tile_rows(a.n), ds_tile_cols(nk));
         return hipGetLastError();
     };
+    if (ds) return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>) : launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true>);
     if constexpr (std::is_same<Tag, bf16_tag>::value) {
         if (!a.causal) switch (option(OPT_DKDV_ABL)) {   // profiling ablations: see the kernel's header comment
             case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 1>);
@@ -592,8 +626,8 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
 
 bool bwd_dkdv_w4_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
 
-hipError_t launch_bwd_dkdv_w4(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
-    return a.dtype == 2 ? launch_dkdv_w4_t<bf16_tag>(a, nlse, ndelta, st) : launch_dkdv_w4_t<f16_tag>(a, nlse, ndelta, st);
+hipError_t launch_bwd_dkdv_w4(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st, void* ds) {
+    return a.dtype == 2 ? launch_dkdv_w4_t<bf16_tag>(a, nlse, ndelta, st, ds) : launch_dkdv_w4_t<f16_tag>(a, nlse, ndelta, st, ds);
 }
 
 }  // namespace fa

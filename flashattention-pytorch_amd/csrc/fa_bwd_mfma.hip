@@ -349,8 +349,33 @@ bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2
 
 // workspace: [nlse (bh*n)] [ndelta (bh*n)] [pad to 256 B] [dq scratch fp32 (bh*n*d): single-kernel (atomic) variant only]
 static size_t row_constants_bytes(int64_t bh, int64_t n) { return (sizeof(float) * 2 * (size_t)bh * n + 255) & ~(size_t)255; }
+// The dS hand-over (d = 128, launches big enough for the stream kernels): the dK/dV kernel stores dS, the dQ kernel is one
+// product over it (fa_bwd_dq_ds.hip) — 5 products instead of 7.  Default without the causal mask (-5 % of the whole step at
+// 256 x 4096 x 128; under the mask the stores cost the dK/dV kernel what the dQ kernel gains: +2 %, so causal launches keep the
+// recomputing dQ pass).  Option dq: 6 = always, 5 / 8 = never.  The (b,h) units are worked through in chunks whose dS fits
+// the chunk size (12 GiB; option ds_chunk_mb), so the workspace is bounded whatever BH is.
+static size_t ds_chunk_bytes() {
+    const int mb = option(OPT_DS_CHUNK_MB);
+    return mb > 0 ? (size_t)mb << 20 : (size_t)12 << 30;
+}
+static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant) {
+    const int dq_opt = option(OPT_DQ), dkdv_opt = option(OPT_DKDV);
+    if (atomic_variant || !bwd_dkdv_w4_supported(dtype, d) || dq_opt == 5 || dq_opt == 8 || (dkdv_opt != 0 && dkdv_opt != 5)) return false;
+    if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || option(OPT_DQ_W4) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
+    if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
+    return dq_opt == 6 || (!causal && !small_grid(bh, n));
+}
+static int64_t ds_chunk_units(int64_t bh, int64_t n) {
+    const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));
+    return fit < bh ? fit : bh;
+}
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {
     return row_constants_bytes(bh, n) + (atomic_variant ? sizeof(float) * (size_t)bh * n * d : 0) + 256;
+}
+// what the dS hand-over wants on top of that (0 where it does not serve the call): a call whose workspace is smaller runs
+// the recomputing dQ pass instead
+size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant) {
+    return bwd_ds_path(dtype, d, bh, n, causal, atomic_variant) ? ds_workspace_bytes(ds_chunk_units(bh, n), n, n) : 0;
 }
 
 template <typename Tag, int D>
@@ -374,6 +399,30 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     // d <= 64: a preparation launch makes them (fa_bwd_dq_mfma.hip, PREP).  FA_DKDV=4 selects the 4-wave dK/dV kernel.
     const int dkdv_env = option(OPT_DKDV);
     const bool split = pad || (!fused && dkdv_env != 4);
+    const size_t ds_extra = pad ? 0 : bwd_ds_extra_bytes(a.bh, a.n, a.d, a.dtype, a.causal != 0, a.fused_dq != 0);
+    if (ds_extra && option(OPT_DQ) == 6 && a.workspace_bytes < bwd_mfma_workspace_bytes(a.bh, a.n, a.d, false) + ds_extra)
+        return hipErrorInvalidValue;   // asked for by option: fail rather than fall back
+    if (ds_extra && a.workspace_bytes >= bwd_mfma_workspace_bytes(a.bh, a.n, a.d, false) + ds_extra) {
+        // row constants, then per chunk of (b,h) units: dK/dV (stores dS), dQ = scale * dS K
+        {
+            ProfScope ps(K_BWD_DELTA, st);
+            hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
+                               (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, (int)a.d, 1.0f / a.scale);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        void* ds = dq_acc;   // behind the row constants (256-byte aligned)
+        const int64_t step = ds_chunk_units(a.bh, a.n);
+        for (int64_t b0 = 0; b0 < a.bh; b0 += step) {
+            BwdArgs c = a;
+            c.bh = a.bh - b0 < step ? a.bh - b0 : step;
+            const size_t eo = (size_t)b0 * a.n * a.d * 2;
+            c.q = (const char*)a.q + eo; c.k = (const char*)a.k + eo; c.v = (const char*)a.v + eo; c.dout = (const char*)a.dout + eo;
+            c.dq = (char*)a.dq + eo; c.dk = (char*)a.dk + eo; c.dv = (char*)a.dv + eo;
+            if ((e = launch_bwd_dkdv_w4(c, nlse + b0 * a.n, ndelta + b0 * a.n, st, ds)) != hipSuccess) return e;
+            if ((e = launch_bwd_dq_ds(c, ds, st)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     if (split && dq_makes_row_constants(a.d)) {
         e = launch_bwd_dq_mfma(a, nlse, ndelta, st);
         if (e != hipSuccess) return e;

@@ -50,7 +50,7 @@ hipError_t ensure_dynamic_smem(const void* kernel, int bytes);
 // Tuning knobs (tile sweep / A-B runs).  Each starts from an environment variable of the same upper-case name with
 // an FA_ prefix (FA_FWD_KB, FA_FWD_STAG, FA_DKDV (4|8), FA_DQ_KT, FA_FWD_RS, FA_DKDV_KREG, FA_FWD_EAGER, FA_FWD_HS, FA_FWD_TPW, FA_DQ_TPW, FA_DKDV_TPW, FA_DQ_NLF, FA_DQ_W4, FA_FWD_ABL, FA_SMALL_GRID, FA_FP8_ROT, FA_DKDV_STG) and can be changed at run time through
 // fa_set_option() so that variants can be interleaved in one process.
-enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_COUNT };
+enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_DS_CHUNK_MB, OPT_COUNT };
 int option(int id);
 int set_option(const char* name, int value);   // returns 0, or -1 for an unknown name
 
@@ -71,12 +71,23 @@ hipError_t launch_fwd_nqnk(const FwdArgs& a, hipStream_t st);
 bool bwd_mfma_supported(int dtype, int64_t d);
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant);   // fp32 dQ scratch only for the single-kernel variant
+// bytes the dS hand-over (fa_bwd_dq_ds.hip) wants on top of that; 0 where it does not serve the call
+size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant);
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);  // 8-wave dK/dV
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st);   // d > 64: also WRITES nlse / ndelta
 inline bool dq_makes_row_constants(int64_t d) { return d > 64; }
 // one wave per SIMD, 64 keys per wave, hand-ordered MFMA stream (fa_bwd_dkdv_w4.hip): d = 128
 bool bwd_dkdv_w4_supported(int dtype, int64_t d);
-hipError_t launch_bwd_dkdv_w4(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);
+// ds != null: the kernel also stores the packed dS tiles there (ds_workspace_bytes) for launch_bwd_dq_ds
+hipError_t launch_bwd_dkdv_w4(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st, void* ds = nullptr);
+// dS hand-over between the dK/dV stream kernel and the dQ product kernel (fa_bwd_dq_ds.hip): 2-KiB tiles of 32 queries x
+// 32 keys, (b,h)-major, then 32-query block, then 32-key block; the key blocks are padded to the dK/dV kernel's 256-key tiles
+inline int ds_tile_rows(int64_t nq) { return (int)((nq + 31) / 32); }
+inline int ds_tile_cols(int64_t nk) { return (int)(8 * ((nk + 255) / 256)); }
+inline size_t ds_workspace_bytes(int64_t bh, int64_t nq, int64_t nk) { return (size_t)bh * ds_tile_rows(nq) * ds_tile_cols(nk) * 2048; }
+// dQ = scale * dS K from the stored dS tiles: d = 128, one pass over dS at HBM rate (no recomputation of S and dP)
+hipError_t launch_bwd_dq_ds(const BwdArgs& a, const void* ds, hipStream_t st);
+
 // the dQ pass in the same shape (fa_bwd_dq_w4.hip): d = 128; writes nlse / ndelta like launch_bwd_dq_mfma at d > 64
 bool bwd_dq_w4_supported(int dtype, int64_t d);
 hipError_t launch_bwd_dq_w4(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st);

@@ -30,7 +30,7 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 EXPORTED_C_SYMBOLS = (
     "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
-    "fa_backward_workspace_bytes", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
+    "fa_backward_workspace_bytes", "fa_backward_workspace_bytes_fast", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
     "fa_set_kernel_mode", "fa_set_option", "fa_debug_trace_buffer", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
     "fa_ex_forward", "fa_ex_backward", "fa_ex_backward_workspace_bytes",
 )
@@ -58,6 +58,8 @@ def _load_library() -> ctypes.CDLL:
     lib.fa3_backward.restype = ci
     lib.fa_backward_workspace_bytes.argtypes = [i64, i64, i64, ci]
     lib.fa_backward_workspace_bytes.restype = sz
+    lib.fa_backward_workspace_bytes_fast.argtypes = [i64, i64, i64, ci, ci]
+    lib.fa_backward_workspace_bytes_fast.restype = sz
     lib.fa3_forward_workspace_bytes.argtypes = [i64, i64, i64, ci, ci]
     lib.fa3_forward_workspace_bytes.restype = sz
     lib.fa3_backward_workspace_bytes.argtypes = [i64, i64, i64, ci, ci]
@@ -184,8 +186,15 @@ def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, ext
         if extra is not None:
             nbytes = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1]))))
         else:
+            nbytes = int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal))))
+        try:
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        except torch.cuda.OutOfMemoryError:
+            # no room for the dS tiles: the minimum workspace makes the library take its recomputing dQ pass
+            if extra is not None or nbytes == int(_lib.fa_backward_workspace_bytes(bh, n, d, code)):
+                raise
             nbytes = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, n, d, code, int(bool(causal)),
                 float(softmax_scale), int(br), int(bc)]

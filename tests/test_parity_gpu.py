@@ -644,3 +644,82 @@ def test_many_small_heads(device):
     assert max_abs(lse.cpu(), rlse) < 1e-3
     for a, b in ((dq, rq), (dk, rk), (dv, rv)):
         torch.testing.assert_close(a.cpu(), b, rtol=5e-2, atol=5e-2)
+
+
+# ---- the dS hand-over backward (csrc/fa_bwd_dq_ds.hip): dK/dV kernel stores dS, dQ = scale * dS K ----
+DS_SHAPES = [(2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
+
+
+@pytest.mark.parametrize("bh,n", DS_SHAPES)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, device):
+    """Option dq = 6 forces the path on launches of any size and under the causal mask (its default is non-causal launches of
+    >= 224 row tiles); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
+    (ds_chunk_mb), so the chunk loop runs too."""
+    import flashattention_lab_cuda as ext
+
+    d = 128
+    q, k, v, do = make_qkv(bh, n, d, dtype, seed=7000 + n)
+    scale = d ** -0.5
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, scale, math_dtype=torch.float64)
+    per_unit_mb = -(-((n + 31) // 32 * 8 * ((n + 255) // 256) * 2048) // (1 << 20))
+    ext.set_option("dq", 6)
+    ext.set_option("ds_chunk_mb", per_unit_mb)
+    try:
+        o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
+    finally:
+        ext.set_option("dq", 0)
+        ext.set_option("ds_chunk_mb", 0)
+    tol = dtype_tolerances(dtype)
+    for name, a, b in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert torch.isfinite(a.float()).all(), name
+        bad = ((a.cpu().double() - b.double()).abs() > tol["atol"] + tol["rtol"] * b.double().abs()).any(dim=-1).nonzero()
+        assert len(bad) == 0, f"{name}: {len(bad)} bad rows, first {bad[:8].tolist()}, last {bad[-4:].tolist()}"
+    # and far inside that bar relative to the gradients' scale (bf16: a few ulps of the largest element)
+    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
+        assert max_abs(a.cpu(), b) < (2e-2 if dtype == torch.bfloat16 else 4e-3) * b.abs().max().item()
+
+
+def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_recomputing_pass(device):
+    """Config 4's per-GPU kind of launch (here 64 units: 64 x 16 row tiles): the default backward takes the dS hand-over (the
+    library profile shows the preparation launch that only it has), dq = 5 the recomputing pass; same results up to summation
+    order; a workspace of the minimum size makes the library fall back by itself."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 64, 4096, 128
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=11, device=device)
+    o, lse = ext.forward(q, k, v, False, d ** -0.5, 64, 128)
+    ext.profile_enable(True)
+    got = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    prof = ext.profile_report()
+    ext.profile_enable(False)
+    assert "bwd_delta" in prof and "bwd_dq_mfma" in prof and "bwd_mfma" in prof, prof
+    ext.set_option("dq", 5)
+    try:
+        ref = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    finally:
+        ext.set_option("dq", 0)
+    for a, b in zip(got, ref):
+        assert max_abs(a, b) <= 2e-2 * b.float().abs().max().item()
+    # checksum identities on the default path at this size: sum_keys dV = sum_queries dO, sum q.dq = sum k.dk
+    dq, dk, dv = got
+    torch.testing.assert_close(dv.float().sum(1), do.float().sum(1), rtol=2e-2, atol=2e-1)
+    sq, sk = (q.float() * dq.float()).sum().item(), (k.float() * dk.float()).sum().item()
+    assert abs(sq - sk) <= 2e-2 * max(abs(sq), abs(sk), 1.0)
+    # the raw entry point with the minimum workspace: recomputing pass, no preparation launch
+    lib = ext._lib
+    nbytes = int(lib.fa_backward_workspace_bytes(bh, n, d, 2))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    dq2, dk2, dv2 = (torch.empty_like(t) for t in (q, k, v))
+    ext.profile_enable(True)
+    rc = lib.fa2_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq2.data_ptr(),
+                          dk2.data_ptr(), dv2.data_ptr(), bh, n, d, 2, 0, d ** -0.5, 64, 128, ws.data_ptr(), nbytes,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    prof2 = ext.profile_report()
+    ext.profile_enable(False)
+    assert rc == 0 and "bwd_delta" not in prof2
+    for a, b in zip((dq2, dk2, dv2), ref):
+        assert torch.equal(a, b)

@@ -49,6 +49,20 @@ def test_dkdv_table_is_the_generators_output_and_within_budget():
     assert where["LADDR"] < min(where[f"ACC({i})"] for i in range(4))
 
 
+def test_dkdv_ds_variant_adds_only_its_four_stores():
+    """The dK/dV kernel's DS variant (dS handed to fa_bwd_dq_ds.hip) issues its four stores in slices 52 .. 55 by hand: that is
+    where the generator puts them, moving nothing else and staying within every gap's budget."""
+    plain, rows = _generated("gen_dkdv_schedule.py")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_dkdv_schedule.py"), "--ds"], check=True, capture_output=True, text=True).stdout
+    ds_rows = [l.strip() for l in out.splitlines() if l.strip().startswith("/*")]
+    assert "0 cycles over budget in 0 gaps" in out
+    stores = {52: "DSST(0,0)", 53: "DSST(0,1)", 54: "DSST(1,0)", 55: "DSST(1,1)"}
+    for s_, (a, b) in enumerate(zip(_ops(rows), _ops(ds_rows))):
+        assert b == a + ([stores[s_]] if s_ in stores else []), (s_, a, b)
+    src = open(os.path.join(CSRC, "fa_bwd_dkdv_w4.hip")).read()
+    assert "if constexpr (DS && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});" in src
+
+
 def test_dq_table_is_the_generators_output_and_within_budget():
     out, rows = _generated("gen_dq_schedule.py")
     assert rows == _embedded("fa_bwd_dq_w4.hip", "dqsched"), "regenerate dqsched::kSched with tools/gen_dq_schedule.py"

@@ -17,7 +17,7 @@ take their share of that gap; what is left is the budget the block's other work 
 A gap that is over its budget stretches by the excess (tools/asm_gaps.py measures a built kernel the same way).  This
 script packs the work greedily, earliest deadline first, and prints the table as C++.
 
-    python tools/gen_dkdv_schedule.py [--prescaled]     # --prescaled: no MUL (K tile already multiplied by c)
+    python tools/gen_dkdv_schedule.py [--prescaled] [--ds]    # --prescaled: no MUL (K tile already multiplied by c)
 """
 import argparse
 
@@ -40,6 +40,7 @@ def budget(S, nop=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--prescaled", action="store_true")
+    ap.add_argument("--ds", action="store_true")
     args = ap.parse_args()
     ops = []   # name, cost, earliest slice, deadline slice, deps (names that must sit in an EARLIER slice), same-slice deps
 
@@ -74,6 +75,11 @@ def main():
     for j in range(4):
         add(f"TADDR({j})", 8, 56, 63)            # two addresses; last transposed request in front of MFMA 56
 
+    if args.ds:
+        for kb in (0, 1):
+            for half in (0, 1):
+                add(f"DSST({kb},{half})", 8, 40, 63, before=tuple(f"SU({kb},{4 * half + m})" for m in range(4)))
+
     placed, where = {S: [] for S in range(64)}, {}
     left = {S: budget(S) for S in range(64)}
     pending = list(ops)
@@ -95,7 +101,7 @@ def main():
                     break
     assert not pending, pending
     over = sum(-v for v in left.values() if v < 0)
-    print(f"// generated by tools/gen_dkdv_schedule.py{' --prescaled' if args.prescaled else ''}: {over} cycles over budget in "
+    print(f"// generated by tools/gen_dkdv_schedule.py{' --prescaled' if args.prescaled else ''}{' --ds' if args.ds else ''}: {over} cycles over budget in "
           f"{sum(1 for v in left.values() if v < 0)} gaps")
     width = max(len(v) for v in placed.values())
     print(f"// slice S (after MFMA S): up to {width} operations")
