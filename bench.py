@@ -261,6 +261,16 @@ def main(argv=None):
                     per_kernel[kname]["achieved_tflops"] = round(alg[kname] / (ms_ / c_ * 1e-3) / 1e12, 1)
                 if kname in traffic:
                     per_kernel[kname]["hbm_bytes"] = traffic[kname]["hbm_bytes"]
+            if "bwd_delta" in prof and "bwd_dq_mfma" in per_kernel and D == 128:
+                # dS hand-over: the dQ kernel is one product over the stored dS tiles, bound by reading them once.
+                # Algorithmic bytes per launch: dS (N^2 * 2 per (b,h), the visible half + diagonal under the mask) + K + dQ.
+                vis = (N + 1) / (2.0 * N) if args.causal else 1.0
+                c_, ms_ = prof["bwd_dq_mfma"]
+                launches_per_step = max(1.0, c_ / max(1, prof.get("fwd_mfma", (c_, 0))[0]))   # > 1: chunks of (b,h) units
+                dq_bytes = bh * (N * N * 2.0 * vis + 2 * N * D * 2.0) / launches_per_step
+                gbps = dq_bytes / (ms_ / c_ * 1e-3) / 1e9
+                per_kernel["bwd_dq_mfma"].update({"bound": "hbm", "algorithmic_bytes_per_launch": dq_bytes, "achieved_GBps": round(gbps, 1),
+                                                  "peak_GBps": 8000.0, "frac": round(gbps / 8000.0, 4)})
             bwd_ms = sum(ms_ / c_ for kname, (c_, ms_) in prof.items() if kname.startswith("bwd"))
             all_ms = sum(ms_ / c_ for kname, (c_, ms_) in prof.items())
             roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",

@@ -30,15 +30,16 @@
 
 namespace fa {
 
-template <typename Tag, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void bwd_dq_ds_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ ds,
+template <typename Tag, bool CAUSAL, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ ds,
                                                            uint16_t* __restrict__ dq, int n, int nk, int nqt, int nqb, int nkb32,
                                                            float scale) {
-    constexpr int D = 128, NDB = 4, BM = 256, SK = 32, NBUF = 6, AHEAD = NBUF - 1;
+    constexpr int D = 128, NDB = 4, BM = 64 * NW, SK = 32, NBUF = NW == 8 ? 3 : 6, AHEAD = NBUF - 1;
     constexpr int K_BYTES = SK * D * 2;             // 8 KiB: the stage's K rows
     constexpr int DS_W = 2 * 2048;                  // 4 KiB: a wave's two dS tiles of the stage
-    constexpr int BUF = K_BYTES + 4 * DS_W;         // 24 KiB
-    constexpr int PIECES = 6;                       // per wave and stage: 2 of K, 2 x 2 of dS
+    constexpr int BUF = K_BYTES + NW * DS_W;        // 24 / 40 KiB
+    constexpr int KP = 8 / NW;                      // K pieces per wave and stage
+    constexpr int PIECES = KP + 4;                  // per wave and stage: K, 2 x 2 of dS
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_ds_kernel(const uint16_t* __res
         const unsigned b = bbase + (unsigned)(t % NBUF) * BUF;
         const bool kl = t < nst;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pc = w + 4 * j;
+        for (int j = 0; j < KP; ++j) {
+            const int pc = w + NW * j;
             dma16_issue(k_rs, b + pc * 1024, kl ? k_voff : kOobOff, __builtin_amdgcn_readfirstlane((SK * t + 4 * pc) * 2 * D));
         }
 #pragma unroll
@@ -159,20 +160,22 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_ds_kernel(const uint16_t* __res
 
 template <typename Tag>
 static hipError_t launch_dq_ds_t(const BwdArgs& a, const void* ds, hipStream_t st) {
-    constexpr int BM = 256;
+    const int nw = option(OPT_DQ_W4) == 3 ? 4 : 8;   // (option dq_w4 = 3 with dq = 6: the 4-wave / 256-row form, for the sweep)
+    const int BM = 64 * nw;
     const int64_t nk = a.nk > 0 ? a.nk : a.n;
     const int nqt = (int)((a.n + BM - 1) / BM);
-    const size_t smem = 6 * (32 * 128 * 2 + 4 * 4096);
+    const size_t smem = nw == 8 ? 3 * (32 * 128 * 2 + 8 * 4096) : 6 * (32 * 128 * 2 + 4 * 4096);
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_BWD_DQ_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, (const uint16_t*)a.k, (const uint16_t*)ds, (uint16_t*)a.dq, (int)a.n, (int)nk,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), smem, st, (const uint16_t*)a.k, (const uint16_t*)ds, (uint16_t*)a.dq, (int)a.n, (int)nk,
                            nqt, ds_tile_rows(a.n), ds_tile_cols(nk), a.scale);
         return hipGetLastError();
     };
-    return a.causal ? launch(bwd_dq_ds_kernel<Tag, true>) : launch(bwd_dq_ds_kernel<Tag, false>);
+    if (nw == 4) return a.causal ? launch(bwd_dq_ds_kernel<Tag, true, 4>) : launch(bwd_dq_ds_kernel<Tag, false, 4>);
+    return a.causal ? launch(bwd_dq_ds_kernel<Tag, true, 8>) : launch(bwd_dq_ds_kernel<Tag, false, 8>);
 }
 
 hipError_t launch_bwd_dq_ds(const BwdArgs& a, const void* ds, hipStream_t st) {

@@ -363,7 +363,7 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (atomic_variant || !bwd_dkdv_w4_supported(dtype, d)) return false;
     // a kernel pinned by option (A/B runs of one pass against another) keeps the other pass as it was: only dq = 6 asks for this path
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
-    if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || option(OPT_DQ_W4) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
+    if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
     return dq_opt == 6 || (!causal && !small_grid(bh, n));
 }

@@ -653,7 +653,8 @@ DS_SHAPES = [(2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
 @pytest.mark.parametrize("bh,n", DS_SHAPES)
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, device):
+@pytest.mark.parametrize("rows", [512, 256])
+def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device):
     """Option dq = 6 forces the path on launches of any size and under the causal mask (its default is non-causal launches of
     >= 224 row tiles); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
     (ds_chunk_mb), so the chunk loop runs too."""
@@ -666,11 +667,13 @@ def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, device):
     per_unit_mb = -(-((n + 31) // 32 * 8 * ((n + 255) // 256) * 2048) // (1 << 20))
     ext.set_option("dq", 6)
     ext.set_option("ds_chunk_mb", per_unit_mb)
+    ext.set_option("dq_w4", 3 if rows == 256 else 0)   # the dQ product kernel's 4-wave / 256-row form (default: 8 waves, 512 rows)
     try:
         o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
     finally:
         ext.set_option("dq", 0)
         ext.set_option("ds_chunk_mb", 0)
+        ext.set_option("dq_w4", 0)
     tol = dtype_tolerances(dtype)
     for name, a, b in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         assert torch.isfinite(a.float()).all(), name

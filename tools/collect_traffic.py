@@ -11,7 +11,7 @@ import json
 import sys
 
 SHORT = {"fwd_mfma_kernel": "fwd_mfma", "fwd_mfma_stag_kernel": "fwd_mfma", "bwd_dkdv_mfma_kernel": "bwd_mfma", "bwd_mfma_kernel": "bwd_mfma",
-         "bwd_dq_mfma_kernel": "bwd_dq_mfma", "bwd_dkdv_w4_kernel": "bwd_mfma", "bwd_dq_w4_kernel": "bwd_dq_mfma", "bwd_prep_kernel": "bwd_delta", "dq_convert_kernel": "bwd_dq_cvt"}
+         "bwd_dq_mfma_kernel": "bwd_dq_mfma", "bwd_dkdv_w4_kernel": "bwd_mfma", "bwd_dq_w4_kernel": "bwd_dq_mfma", "bwd_dq_ds_kernel": "bwd_dq_mfma", "bwd_prep_kernel": "bwd_delta", "dq_convert_kernel": "bwd_dq_cvt"}
 
 
 def mean_by_kernel(path, counter):
