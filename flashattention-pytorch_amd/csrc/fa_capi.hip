@@ -298,12 +298,16 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
         const size_t need = fa3_backward_workspace_bytes(bh, n, d, dtype, 1);
         if (!workspace || workspace_bytes < need || !aligned16({workspace}))
             return fail(FA_ERR_WORKSPACE, "fa3_backward: a 16-byte aligned workspace of %zu bytes is needed, %zu given", need, workspace_bytes);
-        char* qt = reinterpret_cast<char*>(workspace) + base_need;
+        // layout: [round-tripped Q][round-tripped K][pad to 256][the plain backward's workspace: everything that is left, so a
+        // caller who sized it with fa_backward_workspace_bytes_fast's surplus gets the dS hand-over here too]
+        (void)base_need;
+        const size_t slabs = (2 * (size_t)bh * n * d * 2 + 255) & ~(size_t)255;
+        char* qt = reinterpret_cast<char*>(workspace);
         char* kt = qt + (size_t)bh * n * d * 2;
         hipError_t e = fa::launch_fp8_roundtrip(q, k, qt, kt, bh, n, dtype, reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
         return backward_impl("fa3_backward", qt, kt, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
-                             workspace, base_need, stream);
+                             qt + slabs, workspace_bytes - slabs, stream);
     }
     return backward_impl("fa3_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
                          workspace, workspace_bytes, stream);

@@ -185,15 +185,18 @@ def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, ext
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         if extra is not None:
             nbytes = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1]))))
+            # + room for the dS tiles where the backward can use them (the library takes what is left behind its fp8 slabs)
+            nbytes += int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal)))) - int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
         else:
             nbytes = int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal))))
         try:
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         except torch.cuda.OutOfMemoryError:
             # no room for the dS tiles: the minimum workspace makes the library take its recomputing dQ pass
-            if extra is not None or nbytes == int(_lib.fa_backward_workspace_bytes(bh, n, d, code)):
+            small = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1])))) if extra is not None else int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
+            if nbytes == small:
                 raise
-            nbytes = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
+            nbytes = small
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, n, d, code, int(bool(causal)),

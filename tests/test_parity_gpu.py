@@ -668,6 +668,11 @@ def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device)
     ext.set_option("dq", 6)
     ext.set_option("ds_chunk_mb", per_unit_mb)
     ext.set_option("dq_w4", 3 if rows == 256 else 0)   # the dQ product kernel's 4-wave / 256-row form (default: 8 waves, 512 rows)
+    # the workspace the shim is about to get from torch's caching allocator: full of NaN patterns (a dS tile the dK/dV kernel
+    # did not write — blocks the causal mask removes, tiles past a ragged end — must not be read)
+    junk = torch.full((int(ext._lib.fa_backward_workspace_bytes_fast(bh, n, d, 2 if dtype == torch.bfloat16 else 1, int(causal))),), 0xFF,
+                      dtype=torch.uint8, device=device)
+    del junk
     try:
         o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
     finally:

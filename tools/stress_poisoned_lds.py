@@ -28,18 +28,23 @@ except Exception as e:
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 nbad = 0
 for trial in range(6):
-    for (bh, n, d, causal) in ((2, 513, 64, False), (2, 513, 64, True), (1, 513, 128, False), (3, 577, 128, True), (2, 65, 128, False), (2, 130, 64, True)):
+    # (the last four: the dS hand-over backward, option dq = 6 — its dQ kernel counts on out-of-range LDS-DMA pieces zero-filling the
+    # tiles of blocks the causal mask removes)
+    for (bh, n, d, causal, dq_opt) in ((2, 513, 64, False, 0), (2, 513, 64, True, 0), (1, 513, 128, False, 0), (3, 577, 128, True, 0), (2, 65, 128, False, 0), (2, 130, 64, True, 0),
+                                       (3, 577, 128, True, 6), (1, 513, 128, False, 6), (2, 1100, 128, True, 6), (1, 2048 + 31, 128, True, 6)):
         q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=1000 + n + d)
         rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, d ** -0.5, math_dtype=torch.float64)
         qd, kd, vd, dod = (t.cuda() for t in (q, k, v, do))
         if mod is not None: mod.poison(sink.data_ptr())
         o, lse = ext.forward(qd, kd, vd, causal, d ** -0.5, 128, 128)
         if mod is not None: mod.poison(sink.data_ptr())
+        ext.set_option("dq", dq_opt)
         dq, dk, dv = ext.backward(qd, kd, vd, o, dod, lse, causal, d ** -0.5, 128, 128)
+        ext.set_option("dq", 0)
         for name, a, b in (("o", o, ro), ("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
             err = (a.cpu().float() - b.float()).abs().amax(dim=-1)
             bad = ((err > 0.06) | ~torch.isfinite(err)).nonzero()
             if len(bad):
                 nbad += 1
-                print("BAD", trial, bh, n, d, causal, name, "max", err.max().item(), "rows", bad[:10].tolist(), len(bad))
+                print("BAD", trial, bh, n, d, causal, dq_opt, name, "max", err.max().item(), "rows", bad[:10].tolist(), len(bad))
 print("done, bad =", nbad)
