@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // all but this wave's newest tile (4 pieces + 1 row-constant piece) have landed.  DS: the block's four dS stores were
     // issued behind those pieces and count too (vector-memory operations of all kinds retire in issue order); from the
     // stream's second block on the previous block's stores may still be in flight as well: they have a block to complete.
-    // What the stores cost is their issue — 44 cycles each, 7 % of the block, wherever they sit in it (stores into a
-    // private, L2-resident tile cost the same as the real ones; not waiting for them saves nothing: ds_st ablations of
-    // profiles/r02_ds_handover.md).
+    // The stores cost the kernel 7 % wherever they sit in the block (stores into a private, L2-resident tile cost the same as
+    // the real ones; not waiting for them saves nothing; in the nearly empty gaps of the dP' chains they cost the same:
+    // profiles/r02_ds_handover.md) — about a third of it in cycles, the rest in clock: the chip is power-limited.
     auto wait_tiles = [&](bool first_block = false) {
         if (!DS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (first_block) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
