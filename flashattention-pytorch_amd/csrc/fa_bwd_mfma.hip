@@ -350,13 +350,13 @@ bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2
 // workspace: [nlse (bh*n)] [ndelta (bh*n)] [pad to 256 B] [dq scratch fp32 (bh*n*d): single-kernel (atomic) variant only]
 static size_t row_constants_bytes(int64_t bh, int64_t n) { return (sizeof(float) * 2 * (size_t)bh * n + 255) & ~(size_t)255; }
 // The dS hand-over (d = 128, launches big enough for the stream kernels): the dK/dV kernel stores dS, the dQ kernel is one
-// product over it (fa_bwd_dq_ds.hip) — 5 products instead of 7.  Default without the causal mask (-5 % of the whole step at
-// 256 x 4096 x 128; under the mask the stores cost the dK/dV kernel what the dQ kernel gains: +2 %, so causal launches keep the
-// recomputing dQ pass).  Option dq: 6 = always, 5 / 8 = never.  The (b,h) units are worked through in chunks whose dS fits
-// the chunk size (12 GiB; option ds_chunk_mb), so the workspace is bounded whatever BH is.
+// product over it (fa_bwd_dq_ds.hip) — 5 products instead of 7: -5 ... -7 % of the whole step at 256 x 4096 x 128, -2.6 % under
+// the causal mask there, -2 ... -3 % at config 3 (profiles/r02_ds_handover.md).  Option dq: 6 = always (small launches too),
+// 5 / 8 = never.  The (b,h) units are worked through in equal chunks whose dS fits the chunk size (16 GiB; option ds_chunk_mb),
+// so the workspace is bounded whatever BH is.
 static size_t ds_chunk_bytes() {
     const int mb = option(OPT_DS_CHUNK_MB);
-    return mb > 0 ? (size_t)mb << 20 : (size_t)12 << 30;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)16 << 30;
 }
 static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant) {
     const int dq_opt = option(OPT_DQ), dkdv_opt = option(OPT_DKDV);
@@ -365,11 +365,14 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
-    return dq_opt == 6 || (!causal && !small_grid(bh, n));
+    (void)causal;   // (under the mask half of every (b,h)'s tile grid stays unwritten and unread: the layout is the same)
+    return dq_opt == 6 || !small_grid(bh, n);
 }
 static int64_t ds_chunk_units(int64_t bh, int64_t n) {
     const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));
-    return fit < bh ? fit : bh;
+    if (fit >= bh) return bh;
+    const int64_t nch = (bh + fit - 1) / fit;
+    return (bh + nch - 1) / nch;   // equal chunks: a short last one would leave CUs idle
 }
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {
     return row_constants_bytes(bh, n) + (atomic_variant ? sizeof(float) * (size_t)bh * n * d : 0) + 256;
