@@ -13,6 +13,7 @@
 // C/D: col = l&15, row = 4*(l>>4) + reg.
 #include "fa_common.h"
 #include "fa_kernels.h"
+#include <initializer_list>
 
 namespace fa {
 
@@ -31,18 +32,70 @@ __device__ __forceinline__ void load_tile_f32(float* __restrict__ dst, const T* 
     }
 }
 
+// Tile staging, round 2: a thread moves 4 consecutive elements of a row at a time — one 16-byte (f32) or 8-byte (16-bit) load
+// when the row length is a multiple of 4 and the tensor is aligned for it (VEC), four scalar loads otherwise — first into
+// registers (issued BEFORE the tile that is being computed, so the latency hides behind its MFMAs), then into LDS.
+template <typename T> struct Quad { float x[4]; };
+template <typename T, bool VEC>
+__device__ __forceinline__ void load_quad(float (&x)[4], const T* __restrict__ src, int row, int c, int n, int d) {
+    if (VEC) {
+        if (row < n && c < d) {   // d % 4 == 0: the quad is whole or absent
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)row * d + c);
+                x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
+            } else {
+                T t[4];
+                *reinterpret_cast<u32x2*>(t) = *reinterpret_cast<const u32x2*>(src + (size_t)row * d + c);
+                x[0] = to_f32<T>(t[0]); x[1] = to_f32<T>(t[1]); x[2] = to_f32<T>(t[2]); x[3] = to_f32<T>(t[3]);
+            }
+        } else {
+            x[0] = x[1] = x[2] = x[3] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = (row < n && c + i < d) ? to_f32<T>(src[(size_t)row * d + c + i]) : 0.f;
+    }
+}
+// rows r0 .. r0 + ROWS - 1 of a (n, d) matrix as quads in registers: thread t holds quads t, t + NTH, ... (quad q = row q / (DP/4),
+// columns 4 (q % (DP/4)) ..)
+template <typename T, int DP, int ROWS, int NTH, bool VEC>
+struct TileRegs {
+    static constexpr int NQ = (ROWS * (DP / 4) + NTH - 1) / NTH;
+    float x[NQ][4];
+    __device__ __forceinline__ void load(const T* __restrict__ src, int r0, int n, int d) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int qd = threadIdx.x + i * NTH, r = qd / (DP / 4), c = 4 * (qd - r * (DP / 4));
+            if (ROWS * (DP / 4) % NTH == 0 || r < ROWS) load_quad<T, VEC>(x[i], src, r0 + r, c, n, d);
+        }
+    }
+    // row-major image [ROWS][LD]
+    __device__ __forceinline__ void store_rows(float* __restrict__ dst, int LD) const {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int qd = threadIdx.x + i * NTH, r = qd / (DP / 4), c = 4 * (qd - r * (DP / 4));
+            if (ROWS * (DP / 4) % NTH == 0 || r < ROWS) *reinterpret_cast<f32x4*>(dst + r * LD + c) = f32x4{x[i][0], x[i][1], x[i][2], x[i][3]};
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
-// forward: one workgroup = NW waves = 16*NW query rows of one (b,h); key tiles of 32
+// forward: one workgroup = NW waves = 16*NW query rows of one (b,h); key tiles of 32.
+// Round 2: the contraction index of the 16x16x4 MFMA is permuted so that a lane's operands for FOUR consecutive MFMAs are one
+// 16-byte LDS read (lane (lr, lq), step j of super-step S: k = 16 S + 4 lq + j — any permutation will do as long as A and B
+// agree, and the sum stays an f32 fma chain); the wave's Q fragments stay in registers for the whole sweep; in the P V product
+// the P side is read that way (V is contracted over its rows: 4-byte reads, conflict free); the next key tile is fetched into
+// registers while this one is multiplied.  82 LDS reads per key tile and wave instead of 168, none of them in front of a
+// global-memory wait.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NW>
+template <typename T, int DP, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, T* __restrict__ o,
                                                           float* __restrict__ lse, int n, int d, int causal,
                                                           float scale) {
-    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64;
+    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64, NS = DP / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                 // [BM][LD]
-    float* Ks = Qs + BM * LD;         // [BN][LD]
+    float* Ks = smem;                 // [BN][LD]
     float* Vs = Ks + BN * LD;         // [BN][LD]
     float* Ps = Vs + BN * LD;         // [NW][16][PLD]
 
@@ -53,7 +106,17 @@ __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    load_tile_f32<T, DP, LD, NTH>(Qs, q + base, q0, BM, n, d);
+    // this lane's share of its query row: elements 16 S + 4 lq .. + 3 for S = 0 .. NS - 1
+    f32x4 qf[NS];
+    {
+        const int row = q0 + w * 16 + lr;
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            float x[4];
+            load_quad<T, VEC>(x, q + base, row, 16 * S + 4 * lq, n, d);
+            qf[S] = f32x4{x[0], x[1], x[2], x[3]};
+        }
+    }
 
     f32x4 acc[NT];
 #pragma unroll
@@ -64,19 +127,30 @@ __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ 
 
     const int kend = causal ? min(n, q0 + BM) : n;  // keys >= kend are masked for every row of the tile
     float* Pw = Ps + w * 16 * PLD;
+    TileRegs<T, DP, BN, NTH, VEC> kr, vr;
+    kr.load(k + base, 0, n, d);
+    vr.load(v + base, 0, n, d);
 
     for (int k0 = 0; k0 < kend; k0 += BN) {
+        __syncthreads();              // everybody is done with the previous tile's images
+        kr.store_rows(Ks, LD);
+        vr.store_rows(Vs, LD);
         __syncthreads();
-        load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BN, n, d);
-        load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BN, n, d);
-        __syncthreads();
+        if (k0 + BN < kend) {         // the next tile: in flight during this one's products
+            kr.load(k + base, k0 + BN, n, d);
+            vr.load(v + base, k0 + BN, n, d);
+        }
 
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int s = 0; s < DP / 4; ++s) {
-            const float a = Qs[(w * 16 + lr) * LD + 4 * s + lq];
-            s0 = MFMA_F32(a, Ks[lr * LD + 4 * s + lq], s0);
-            s1 = MFMA_F32(a, Ks[(16 + lr) * LD + 4 * s + lq], s1);
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ks + lr * LD + 16 * S + 4 * lq);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ks + (16 + lr) * LD + 16 * S + 4 * lq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0 = MFMA_F32(qf[S][j], b0[j], s0);
+                s1 = MFMA_F32(qf[S][j], b1[j], s1);
+            }
         }
         const int key0 = k0 + lr, key1 = k0 + 16 + lr;
 #pragma unroll
@@ -106,12 +180,14 @@ __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ 
             Pw[(lq * 4 + i) * PLD + lr] = p0;
             Pw[(lq * 4 + i) * PLD + 16 + lr] = p1;
         }
-        __syncthreads();
+        // (Pw is wave-private: no workgroup barrier, the LDS operations of a wave execute in order)
 #pragma unroll
-        for (int s = 0; s < BN / 4; ++s) {
-            const float a = Pw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BN / 16; ++S) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Pw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Vs[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA_F32(a[j], Vs[(16 * S + 4 * lq + j) * LD + 16 * t + lr], acc[t]);
         }
     }
 
@@ -339,18 +415,30 @@ static hipError_t set_smem(K kern, size_t bytes) {
     return ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)bytes);
 }
 
+// VEC: rows of a multiple of 4 elements in tensors aligned for 4-element loads (16 bytes for f32, 8 for the 16-bit types)
+template <typename T>
+static bool quad_loads_ok(int64_t d, std::initializer_list<const void*> ps) {
+    if (d % 4) return false;
+    for (const void* p_ : ps)
+        if (reinterpret_cast<uintptr_t>(p_) % (4 * sizeof(T))) return false;
+    return true;
+}
+
 template <typename T, int DP, int NW>
 static hipError_t launch_fwd_f32_t(const FwdArgs& a, hipStream_t st) {
     constexpr int LD = DP + 4;
-    const size_t smem = sizeof(float) * ((16 * NW + 64) * LD + NW * 16 * 36);
-    auto kern = fwd_f32_kernel<T, DP, NW>;
-    hipError_t e = set_smem(kern, smem);
-    if (e != hipSuccess) return e;
+    const size_t smem = sizeof(float) * (64 * LD + NW * 16 * 36);
+    const bool vec = quad_loads_ok<T>(a.d, {a.q, a.k, a.v});
     dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
     ProfScope ps(K_FWD_F32, st);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v, (T*)a.o, a.lse,
-                       (int)a.n, (int)a.d, a.causal, a.scale);
-    return hipGetLastError();
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = set_smem(kern, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v, (T*)a.o, a.lse,
+                           (int)a.n, (int)a.d, a.causal, a.scale);
+        return hipGetLastError();
+    };
+    return vec ? launch(fwd_f32_kernel<T, DP, NW, true>) : launch(fwd_f32_kernel<T, DP, NW, false>);
 }
 
 template <typename T, int DP, int NW>
