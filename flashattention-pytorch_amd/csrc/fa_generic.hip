@@ -100,8 +100,17 @@ __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ 
     float* Ps = Vs + BN * LD;         // [NW][16][PLD]
 
     const int ntile = (n + BM - 1) / BM;
-    const int bh = blockIdx.x / ntile;
-    const int q0 = (blockIdx.x - bh * ntile) * BM;
+    // Under the causal mask a workgroup takes a heavy and a light tile (TILE and ntile - 1 - TILE): every workgroup then
+    // carries the same number of inner tiles (launches of a few rounds of workgroups ended with a tail as long as a quarter
+    // of the kernel: 45 % occupancy at 64 x 2048).
+    const int npair = causal ? (ntile + 1) / 2 : ntile;
+    const int bh = blockIdx.x / npair;
+    const int jp = blockIdx.x - bh * npair;
+    for (int half = 0; half < (causal ? 2 : 1); ++half) {
+    const int tq_ = (causal && half == 0) ? ntile - 1 - jp : jp;
+    if (half == 1 && jp >= ntile - 1 - jp) break;   // odd tile count: the middle tile is its own pair
+    if (half == 1) __syncthreads();                 // the LDS images are about to be refilled
+    const int q0 = tq_ * BM;
     const size_t base = (size_t)bh * n * d;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_f32_kernel(const T* __restrict__ 
             if (lr == 0) lse[(size_t)bh * n + row] = m[i] + logf(l[i]);
         }
     }
+    }   // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,36 +238,66 @@ __global__ __launch_bounds__(256) void delta_kernel(const T* __restrict__ o, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward dK/dV: one workgroup = NW waves = 16*NW keys (resident in LDS); loops over 32-row Q tiles
+// backward dK/dV: one workgroup = NW waves = 16*NW keys; loops over 32-row Q tiles.
 // S^T[key][q] and dP^T[key][q] are computed with the key on the MFMA row so that dK/dV accumulate
 // per wave without any cross-workgroup sum.   (csrc/fa2/fa2_bwd.cu:70-109)
+// Round 2, as the forward: the wave's K and V rows are register fragments for the whole sweep (KREG; the 256-wide tiles keep
+// them in LDS and read them 16 bytes at a time), Q / dO rows are read 16 bytes at a time (permuted contraction index), the
+// next Q / dO tile is fetched into registers during the products, P^T and dS^T are wave-private in LDS (no workgroup barrier
+// between writing and reading them).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NW>
+template <typename T, int DP, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void bwd_dkdv_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                const T* __restrict__ v, const T* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta, T* __restrict__ dk,
                                                                T* __restrict__ dv, int n, int d, int causal,
                                                                float scale) {
-    constexpr int LD = DP + 4, BK = 16 * NW, BQ = 32, NT = DP / 16, PLD = BQ + 4, NTH = NW * 64;
+    constexpr int LD = DP + 4, BK = 16 * NW, BQ = 32, NT = DP / 16, PLD = BQ + 4, NTH = NW * 64, NS = DP / 16;
+    constexpr bool KREG = DP <= 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                   // [BK][LD]
-    float* Vs = Ks + BK * LD;           // [BK][LD]
-    float* Qs = Vs + BK * LD;           // [BQ][LD]
+    float* Qs = smem;                   // [BQ][LD]
     float* Os = Qs + BQ * LD;           // [BQ][LD]  (dO)
     float* Pt = Os + BQ * LD;           // [NW][16][PLD]   P^T
     float* St = Pt + NW * 16 * PLD;     // [NW][16][PLD]   dS^T
     float* Ls = St + NW * 16 * PLD;     // [BQ] lse, then [BQ] delta
+    float* Ks = Ls + 2 * BQ;            // [BK][LD], [BK][LD] (V): only when !KREG
 
     const int ntile = (n + BK - 1) / BK;
-    const int bh = blockIdx.x / ntile;
-    const int k0 = (blockIdx.x - bh * ntile) * BK;
+    // Under the causal mask a workgroup takes a heavy and a light tile (TILE and ntile - 1 - TILE): every workgroup then
+    // carries the same number of inner tiles (launches of a few rounds of workgroups ended with a tail as long as a quarter
+    // of the kernel: 45 % occupancy at 64 x 2048).
+    const int npair = causal ? (ntile + 1) / 2 : ntile;
+    const int bh = blockIdx.x / npair;
+    const int jp = blockIdx.x - bh * npair;
+    for (int half = 0; half < (causal ? 2 : 1); ++half) {
+    const int tq_ = (causal && half == 1) ? ntile - 1 - jp : jp   /* key tiles: the first ones see the most rows */;
+    if (half == 1 && jp >= ntile - 1 - jp) break;   // odd tile count: the middle tile is its own pair
+    if (half == 1) __syncthreads();                 // the LDS images are about to be refilled
+    const int k0 = tq_ * BK;
     const size_t base = (size_t)bh * n * d;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BK, n, d);
-    load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BK, n, d);
+    f32x4 kf[KREG ? NS : 1], vf[KREG ? NS : 1];
+    if constexpr (KREG) {
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            float x[4];
+            load_quad<T, VEC>(x, k + base, k0 + w * 16 + lr, 16 * S + 4 * lq, n, d);
+            kf[S] = f32x4{x[0], x[1], x[2], x[3]};
+            load_quad<T, VEC>(x, v + base, k0 + w * 16 + lr, 16 * S + 4 * lq, n, d);
+            vf[S] = f32x4{x[0], x[1], x[2], x[3]};
+        }
+    } else {
+        TileRegs<T, DP, BK, NTH, VEC> t;
+        t.load(k + base, k0, n, d);
+        t.store_rows(Ks, LD);
+        t.load(v + base, k0, n, d);
+        t.store_rows(Ks + BK * LD, LD);
+    }
+    const float* Kw = Ks + (w * 16 + lr) * LD + 4 * lq;
+    const float* Vw = Kw + BK * LD;
 
     f32x4 dka[NT], dva[NT];
 #pragma unroll
@@ -266,23 +306,40 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkdv_f32_kernel(const T* __restri
     float* Sw = St + w * 16 * PLD;
 
     const int qstart = causal ? (k0 / BQ) * BQ : 0;  // rows < k0 see none of this tile's keys
-    for (int r0 = qstart; r0 < n; r0 += BQ) {
-        __syncthreads();
-        load_tile_f32<T, DP, LD, NTH>(Qs, q + base, r0, BQ, n, d);
-        load_tile_f32<T, DP, LD, NTH>(Os, dout + base, r0, BQ, n, d);
+    TileRegs<T, DP, BQ, NTH, VEC> qr, orr;
+    float lreg = 0.f, dreg = 0.f;
+    auto fetch = [&](int r0) {
+        qr.load(q + base, r0, n, d);
+        orr.load(dout + base, r0, n, d);
         if (threadIdx.x < BQ) {
             const int r = r0 + threadIdx.x;
-            Ls[threadIdx.x] = r < n ? lse[(size_t)bh * n + r] : 0.f;
-            Ls[BQ + threadIdx.x] = r < n ? delta[(size_t)bh * n + r] : 0.f;
+            lreg = r < n ? lse[(size_t)bh * n + r] : 0.f;
+            dreg = r < n ? delta[(size_t)bh * n + r] : 0.f;
         }
+    };
+    if (qstart < n) fetch(qstart);
+    for (int r0 = qstart; r0 < n; r0 += BQ) {
         __syncthreads();
+        qr.store_rows(Qs, LD);
+        orr.store_rows(Os, LD);
+        if (threadIdx.x < BQ) { Ls[threadIdx.x] = lreg; Ls[BQ + threadIdx.x] = dreg; }
+        __syncthreads();
+        if (r0 + BQ < n) fetch(r0 + BQ);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int s = 0; s < DP / 4; ++s) {
-                st = MFMA_F32(Ks[(w * 16 + lr) * LD + 4 * s + lq], Qs[(qb * 16 + lr) * LD + 4 * s + lq], st);
-                dpt = MFMA_F32(Vs[(w * 16 + lr) * LD + 4 * s + lq], Os[(qb * 16 + lr) * LD + 4 * s + lq], dpt);
+#pragma unroll
+            for (int S = 0; S < NS; ++S) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(Qs + (qb * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bo = *reinterpret_cast<const f32x4*>(Os + (qb * 16 + lr) * LD + 16 * S + 4 * lq);
+                f32x4 ak, av;
+                if constexpr (KREG) { ak = kf[S]; av = vf[S]; }
+                else { ak = *reinterpret_cast<const f32x4*>(Kw + 16 * S); av = *reinterpret_cast<const f32x4*>(Vw + 16 * S); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st = MFMA_F32(ak[j], bq[j], st);
+                    dpt = MFMA_F32(av[j], bo[j], dpt);
+                }
             }
             const int row = r0 + qb * 16 + lr;  // query index (MFMA column)
             const float lq_ = Ls[qb * 16 + lr], dl_ = Ls[BQ + qb * 16 + lr];
@@ -295,16 +352,18 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkdv_f32_kernel(const T* __restri
                 Sw[(lq * 4 + i) * PLD + qb * 16 + lr] = p * (dpt[i] - dl_);
             }
         }
-        __syncthreads();
+        // (P^T, dS^T are wave-private: the LDS operations of a wave execute in order)
 #pragma unroll
-        for (int s = 0; s < BQ / 4; ++s) {
-            const float ap = Pw[lr * PLD + 4 * s + lq];
-            const float as = Sw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BQ / 16; ++S) {
+            const f32x4 ap = *reinterpret_cast<const f32x4*>(Pw + lr * PLD + 16 * S + 4 * lq);
+            const f32x4 as = *reinterpret_cast<const f32x4*>(Sw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                dva[t] = MFMA_F32(ap, Os[(4 * s + lq) * LD + 16 * t + lr], dva[t]);
-                dka[t] = MFMA_F32(as, Qs[(4 * s + lq) * LD + 16 * t + lr], dka[t]);
-            }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dva[t] = MFMA_F32(ap[j], Os[(16 * S + 4 * lq + j) * LD + 16 * t + lr], dva[t]);
+                    dka[t] = MFMA_F32(as[j], Qs[(16 * S + 4 * lq + j) * LD + 16 * t + lr], dka[t]);
+                }
         }
     }
 #pragma unroll
@@ -321,35 +380,63 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkdv_f32_kernel(const T* __restri
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward dQ: one workgroup = NW waves = 16*NW query rows; loops over 32-key tiles (deterministic,
-// no atomics: S and dP are recomputed a second time here)
+// no atomics: S and dP are recomputed a second time here).  Round 2: the wave's Q and dO rows are register fragments (QREG; the
+// 256-wide tiles keep them in LDS), K / V rows are read 16 bytes at a time, the next K / V tile is fetched during the products.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DP, int NW>
+template <typename T, int DP, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                              const T* __restrict__ v, const T* __restrict__ dout,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dq,
                                                              int n, int d, int causal, float scale) {
-    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64;
+    constexpr int LD = DP + 4, BM = 16 * NW, BN = 32, NT = DP / 16, PLD = BN + 4, NTH = NW * 64, NS = DP / 16;
+    constexpr bool QREG = DP <= 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                // [BM][LD]
-    float* Os = Qs + BM * LD;        // [BM][LD]  (dO)
-    float* Ks = Os + BM * LD;        // [BN][LD]
+    float* Ks = smem;                // [BN][LD]
     float* Vs = Ks + BN * LD;        // [BN][LD]
     float* Ss = Vs + BN * LD;        // [NW][16][PLD]  dS
+    float* Qs = Ss + NW * 16 * PLD;  // [BM][LD], [BM][LD] (dO): only when !QREG
 
     const int ntile = (n + BM - 1) / BM;
-    const int bh = blockIdx.x / ntile;
-    const int q0 = (blockIdx.x - bh * ntile) * BM;
+    // Under the causal mask a workgroup takes a heavy and a light tile (TILE and ntile - 1 - TILE): every workgroup then
+    // carries the same number of inner tiles (launches of a few rounds of workgroups ended with a tail as long as a quarter
+    // of the kernel: 45 % occupancy at 64 x 2048).
+    const int npair = causal ? (ntile + 1) / 2 : ntile;
+    const int bh = blockIdx.x / npair;
+    const int jp = blockIdx.x - bh * npair;
+    for (int half = 0; half < (causal ? 2 : 1); ++half) {
+    const int tq_ = (causal && half == 0) ? ntile - 1 - jp : jp;
+    if (half == 1 && jp >= ntile - 1 - jp) break;   // odd tile count: the middle tile is its own pair
+    if (half == 1) __syncthreads();                 // the LDS images are about to be refilled
+    const int q0 = tq_ * BM;
     const size_t base = (size_t)bh * n * d;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    load_tile_f32<T, DP, LD, NTH>(Qs, q + base, q0, BM, n, d);
-    load_tile_f32<T, DP, LD, NTH>(Os, dout + base, q0, BM, n, d);
+    f32x4 qf[QREG ? NS : 1], of[QREG ? NS : 1];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            float x[4];
+            load_quad<T, VEC>(x, q + base, q0 + w * 16 + lr, 16 * S + 4 * lq, n, d);
+            qf[S] = f32x4{x[0], x[1], x[2], x[3]};
+            load_quad<T, VEC>(x, dout + base, q0 + w * 16 + lr, 16 * S + 4 * lq, n, d);
+            of[S] = f32x4{x[0], x[1], x[2], x[3]};
+        }
+    } else {
+        TileRegs<T, DP, BM, NTH, VEC> t;
+        t.load(q + base, q0, n, d);
+        t.store_rows(Qs, LD);
+        t.load(dout + base, q0, n, d);
+        t.store_rows(Qs + BM * LD, LD);
+    }
+    const float* Qw = Qs + (w * 16 + lr) * LD + 4 * lq;
+    const float* Ow = Qw + BM * LD;
 
     float lrow[4], drow[4];
 #pragma unroll
@@ -364,18 +451,33 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict
     float* Sw = Ss + w * 16 * PLD;
 
     const int kend = causal ? min(n, q0 + BM) : n;
+    TileRegs<T, DP, BN, NTH, VEC> kr, vr;
+    kr.load(k + base, 0, n, d);
+    vr.load(v + base, 0, n, d);
     for (int k0 = 0; k0 < kend; k0 += BN) {
         __syncthreads();
-        load_tile_f32<T, DP, LD, NTH>(Ks, k + base, k0, BN, n, d);
-        load_tile_f32<T, DP, LD, NTH>(Vs, v + base, k0, BN, n, d);
+        kr.store_rows(Ks, LD);
+        vr.store_rows(Vs, LD);
         __syncthreads();
+        if (k0 + BN < kend) {
+            kr.load(k + base, k0 + BN, n, d);
+            vr.load(v + base, k0 + BN, n, d);
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int ks = 0; ks < DP / 4; ++ks) {
-                s = MFMA_F32(Qs[(w * 16 + lr) * LD + 4 * ks + lq], Ks[(nb * 16 + lr) * LD + 4 * ks + lq], s);
-                dp = MFMA_F32(Os[(w * 16 + lr) * LD + 4 * ks + lq], Vs[(nb * 16 + lr) * LD + 4 * ks + lq], dp);
+#pragma unroll
+            for (int S = 0; S < NS; ++S) {
+                const f32x4 bk = *reinterpret_cast<const f32x4*>(Ks + (nb * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Vs + (nb * 16 + lr) * LD + 16 * S + 4 * lq);
+                f32x4 aq, ao;
+                if constexpr (QREG) { aq = qf[S]; ao = of[S]; }
+                else { aq = *reinterpret_cast<const f32x4*>(Qw + 16 * S); ao = *reinterpret_cast<const f32x4*>(Ow + 16 * S); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s = MFMA_F32(aq[j], bk[j], s);
+                    dp = MFMA_F32(ao[j], bv[j], dp);
+                }
             }
             const int key = k0 + nb * 16 + lr;
 #pragma unroll
@@ -386,12 +488,14 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict
                 Sw[(lq * 4 + i) * PLD + nb * 16 + lr] = p * (dp[i] - drow[i]);
             }
         }
-        __syncthreads();
+        // (dS is wave-private: no workgroup barrier)
 #pragma unroll
-        for (int s = 0; s < BN / 4; ++s) {
-            const float a = Sw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BN / 16; ++S) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Sw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Ks[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA_F32(a[j], Ks[(16 * S + 4 * lq + j) * LD + 16 * t + lr], acc[t]);
         }
     }
 #pragma unroll
@@ -405,6 +509,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_f32_kernel(const T* __restrict
             }
         }
     }
+    }   // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +534,8 @@ static hipError_t launch_fwd_f32_t(const FwdArgs& a, hipStream_t st) {
     constexpr int LD = DP + 4;
     const size_t smem = sizeof(float) * (64 * LD + NW * 16 * 36);
     const bool vec = quad_loads_ok<T>(a.d, {a.q, a.k, a.v});
-    dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+    const int64_t nt = (a.n + 16 * NW - 1) / (16 * NW);
+    dim3 grid((unsigned)((a.causal ? (nt + 1) / 2 : nt) * a.bh));   // causal: a heavy and a light tile per workgroup
     ProfScope ps(K_FWD_F32, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = set_smem(kern, smem);
@@ -444,8 +550,10 @@ static hipError_t launch_fwd_f32_t(const FwdArgs& a, hipStream_t st) {
 template <typename T, int DP, int NW>
 static hipError_t launch_bwd_f32_t(const BwdArgs& a, hipStream_t st) {
     constexpr int LD = DP + 4;
+    constexpr bool REG = DP <= 128;   // the wave's own rows as register fragments (else a second pair of LDS tiles)
     float* delta = reinterpret_cast<float*>(a.workspace);
     const long long rows = (long long)a.bh * a.n;
+    const bool vec = quad_loads_ok<T>(a.d, {a.q, a.k, a.v, a.dout});
     {
         ProfScope ps(K_BWD_DELTA, st);
         hipLaunchKernelGGL(delta_kernel<T>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, (const T*)a.o,
@@ -453,30 +561,34 @@ static hipError_t launch_bwd_f32_t(const BwdArgs& a, hipStream_t st) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    const int64_t nt = (a.n + 16 * NW - 1) / (16 * NW);
+    dim3 grid((unsigned)((a.causal ? (nt + 1) / 2 : nt) * a.bh));   // causal: a heavy and a light tile per workgroup
     {
-        const size_t smem = sizeof(float) * ((2 * 16 * NW + 64) * LD + 2 * NW * 16 * 36 + 64);
-        auto kern = bwd_dkdv_f32_kernel<T, DP, NW>;
-        e = set_smem(kern, smem);
-        if (e != hipSuccess) return e;
-        dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+        const size_t smem = sizeof(float) * ((64 + (REG ? 0 : 2 * 16 * NW)) * LD + 2 * NW * 16 * 36 + 64);
         ProfScope ps(K_BWD_DKDV_F32, st);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
-                           (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dk, (T*)a.dv, (int)a.n, (int)a.d,
-                           a.causal, a.scale);
-        e = hipGetLastError();
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e2 = set_smem(kern, smem);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
+                               (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dk, (T*)a.dv, (int)a.n, (int)a.d,
+                               a.causal, a.scale);
+            return hipGetLastError();
+        };
+        e = vec ? launch(bwd_dkdv_f32_kernel<T, DP, NW, true>) : launch(bwd_dkdv_f32_kernel<T, DP, NW, false>);
         if (e != hipSuccess) return e;
     }
     {
-        const size_t smem = sizeof(float) * ((2 * 16 * NW + 64) * LD + NW * 16 * 36);
-        auto kern = bwd_dq_f32_kernel<T, DP, NW>;
-        e = set_smem(kern, smem);
-        if (e != hipSuccess) return e;
-        dim3 grid((unsigned)(((a.n + 16 * NW - 1) / (16 * NW)) * a.bh));
+        const size_t smem = sizeof(float) * ((64 + (REG ? 0 : 2 * 16 * NW)) * LD + NW * 16 * 36);
         ProfScope ps(K_BWD_DQ_F32, st);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
-                           (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dq, (int)a.n, (int)a.d, a.causal,
-                           a.scale);
-        e = hipGetLastError();
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e2 = set_smem(kern, smem);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, (const T*)a.q, (const T*)a.k, (const T*)a.v,
+                               (const T*)a.dout, a.lse, (const float*)delta, (T*)a.dq, (int)a.n, (int)a.d, a.causal,
+                               a.scale);
+            return hipGetLastError();
+        };
+        e = vec ? launch(bwd_dq_f32_kernel<T, DP, NW, true>) : launch(bwd_dq_f32_kernel<T, DP, NW, false>);
     }
     return e;
 }

@@ -51,6 +51,21 @@ def test_accumulation_chain_and_unrelated_work_are_fine():
     assert len(audit.audit_text(_ins([MFMA, bad, "s_endpgm"]))[1]) >= 1
 
 
+def test_f32_forms_may_take_a_result_as_c_operand_after_passes_minus_two():
+    """LLVM's SMFMA -> overlapped SrcC rule (hipcc's own code uses it): 8 passes -> 6 states; as A / B operand or for any
+    other reader the full distance (8 + 2) holds; the 16-bit (XDL) forms have no such relaxation here."""
+    prod = "v_mfma_f32_16x16x4_f32 a[8:11], v9, v120, a[8:11]"
+    as_c = "v_mfma_f32_16x16x4_f32 a[28:31], v9, v120, a[8:11]"
+    as_b = "v_mfma_f32_16x16x4_f32 a[28:31], v9, a8, a[28:31]"
+    assert audit.audit_text(_ins([prod, "s_nop 5", as_c, "s_nop 15", "s_endpgm"]))[1] == []
+    # (closer than that it cannot get: the matrix pipe is in order, the consumer issues 7 states behind the producer at the earliest)
+    assert audit.audit_text(_ins([prod, as_c, "s_nop 15", "s_endpgm"]))[1] == []
+    assert len(audit.audit_text(_ins([prod, "s_nop 5", as_b, "s_nop 15", "s_endpgm"]))[1]) == 1
+    assert len(audit.audit_text(_ins([prod, "s_nop 5", as_c, "v_accvgpr_read_b32 v1, a8", "s_nop 15", "s_endpgm"]))[1]) == 1   # still a reader too early
+    xdl_c = "v_mfma_f32_32x32x16_bf16 v[40:55], v[16:19], v[20:23], v[0:15]"
+    assert len(audit.audit_text(_ins([MFMA, "s_nop 5", xdl_c, "s_nop 15", "s_endpgm"]))[1]) >= 1
+
+
 def test_branch_targets_are_followed():
     # the consumer sits at the branch target, 2 states after the MFMA
     text = HEAD

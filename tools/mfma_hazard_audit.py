@@ -10,6 +10,9 @@ embedded in libfa_mi355x.so and checks, for EVERY v_mfma (asm or builtin):
       destination tile — other than an MFMA that takes the whole tile as its C operand and writes it back (an
       accumulation chain: no wait states needed) — at least passes + 3 wait states (passes + 2 for the f32-input forms) must lie
       (LLVM's GFX940 rule "XDL write VGPR -> VALU / memory / export read or write", the number hipcc itself pads to).
+      One relaxation, LLVM's "SMFMA write VGPR -> overlapped SrcC of an SMFMA": the f32-input forms (v_mfma_f32_*_f32) are not
+      XDL operations, and another of them may take such a result as its C operand alone (not as A / B, not overwriting it) after
+      passes - 2 states — hipcc's own code does (fa_generic.hip carries one tile as the initial value of several accumulators).
   R2  VALU-written operand -> MFMA: an MFMA may not read, as A or B operand, a register that a VALU instruction wrote
       in the previous instruction slot pair (2 wait states: fa_common.h's mfma32_v carries an `s_nop 1` for it).
 
@@ -134,7 +137,7 @@ def audit_function(name, ins, verbose):
     index = {x.addr: i for i, x in enumerate(ins)}
     viol, n_mfma, min_slack = [], 0, None
 
-    def scan(i0, need, dst, t, pipe_free, seen):
+    def scan(i0, need, dst, t, pipe_free, seen, need_c=None):
         """walk forward from instruction i0 at time t (wait states since the producer issued; the matrix pipe is busy
         until pipe_free); return (states elapsed, offender) for the first consumer found too early, or None"""
         i = i0
@@ -147,7 +150,10 @@ def audit_function(name, ins, verbose):
                 if t >= need:
                     return None
                 if x.regs & dst:
-                    return (t, x)
+                    c_only = (need_c is not None and x.mn.endswith("_f32") and len(x.srcs) == 3 and (x.srcs[2] & dst)
+                              and not ((x.srcs[0] | x.srcs[1] | x.dst) & dst))
+                    if not (c_only and t >= need_c):
+                        return (t, x)
                 pipe_free = t + passes_of(x.mn)      # (t + 1) + passes - 1
                 t += 1
                 i += 1
@@ -160,7 +166,7 @@ def audit_function(name, ins, verbose):
                 key = (index[x.target], t)
                 if key not in seen:
                     seen.add(key)
-                    r = scan(index[x.target], need, dst, t + x.states, pipe_free, seen)
+                    r = scan(index[x.target], need, dst, t + x.states, pipe_free, seen, need_c)
                     if r is not None:
                         return r
                 if x.mn == "s_branch":
@@ -174,10 +180,11 @@ def audit_function(name, ins, verbose):
             continue
         n_mfma += 1
         # XDL (16 / 8-bit inputs): passes + 3; the f32-input forms are not XDL ops: passes + 2 (LLVM GFX940 SMFMA rule)
-        need = passes_of(x.mn) + (2 if x.mn.endswith("_f32") and "x2_f32" in x.mn or x.mn.endswith("x4_f32") else 3)
+        smfma = x.mn.endswith("x2_f32") or x.mn.endswith("x4_f32")
+        need = passes_of(x.mn) + (2 if smfma else 3)
         # t = wait states BETWEEN the producer and the instruction looked at (LLVM's count); the pipe holds the
         # producer for `passes` states from its own issue slot
-        r = scan(i + 1, need, x.dst, 0, passes_of(x.mn) - 1, set())
+        r = scan(i + 1, need, x.dst, 0, passes_of(x.mn) - 1, set(), passes_of(x.mn) - 2 if smfma else None)
         if r is not None:
             viol.append(f"R1 {name}: {x.mn} {x.ops.split(',')[0]} @0x{x.addr:x}: consumer `{r[1].mn} {r[1].ops}` "
                         f"@0x{r[1].addr:x} after {r[0]} wait states, {need} needed")
