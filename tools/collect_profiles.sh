@@ -5,6 +5,7 @@
 # stats of the bench command, PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters; counters in their own runs, never
 # combined with trace domains other than --kernel-trace), the fp8 bench and one sweep of the reference-shaped harness.
 set -u
+rm -rf "$PWD/gpurun_out/prof_${1:-r02}"   # a second collection would mix its run directories with the first one's
 R=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p "$OUT"
