@@ -585,6 +585,36 @@ def test_misaligned_storage_offset_takes_the_scalar_path(device):
         torch.testing.assert_close(a.cpu(), b, rtol=5e-2, atol=5e-2)
 
 
+@pytest.mark.parametrize("dtype,d,shift", [(torch.float32, 20, 0), (torch.float32, 20, 1), (torch.float32, 10, 0), (torch.float32, 128, 3),
+                                           (torch.bfloat16, 12, 0), (torch.bfloat16, 12, 1), (torch.float16, 36, 2), (torch.float16, 100, 0)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_exact_path_load_forms(dtype, d, shift, causal, device):
+    """The exact-f32 kernels (csrc/fa_generic.hip) fetch tiles four elements at a time where rows and storage allow it (16-byte
+    loads of f32, 8-byte loads of 16-bit elements) and element by element otherwise: row lengths that are / are not multiples of 4,
+    storage offsets that break the alignment, several key tiles, an odd number of row tiles (the causal heavy + light pairing
+    leaves the middle tile alone)."""
+    bh, n = 2, 330
+    q, k, v, do = make_qkv(bh, n, d, dtype, seed=90 + d + shift)
+
+    def shifted(t):
+        if shift == 0:
+            return t.to(device)
+        buf = torch.empty(t.numel() + shift, dtype=t.dtype, device=device)
+        buf[shift:].copy_(t.reshape(-1))
+        return buf[shift:].view(t.shape)
+
+    scale = d ** -0.5
+    o, lse, dq, dk, dv = _run(2, shifted(q), shifted(k), shifted(v), causal, scale, do=shifted(do))
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, scale, math_dtype=torch.float64)
+    tol = dtype_tolerances(dtype)
+    torch.testing.assert_close(o.cpu(), ro, **tol)
+    torch.testing.assert_close(lse.cpu(), rlse, rtol=1e-3, atol=1e-3)
+    for a, b in ((dq, rq), (dk, rk), (dv, rv)):
+        torch.testing.assert_close(a.cpu(), b, **tol)
+    if dtype == torch.float32:
+        assert max(max_abs(o.cpu(), ro), max_abs(dq.cpu(), rq), max_abs(dk.cpu(), rk), max_abs(dv.cpu(), rv)) < 1e-4
+
+
 def test_forward_backward_capture_into_a_hip_graph(device):
     """The launch path does no allocation, sync or memcpy of its own, so a caller can capture forward + backward into
     a HIP graph and replay it (cdna guide §6 Guideline 9)."""
