@@ -379,6 +379,14 @@ hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
         return launch_bwd_mfma(BwdArgs{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale,
                                        a.workspace, ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
     }
+    // the same for what the 16-bit kernels do not take (fp32 tensors, head dims that are not a multiple of 8): the plain path's
+    // exact-f32 kernels (fa_generic.hip: register fragments, 16-byte operand reads — 2.5 x the rate of the kernels below)
+    if ((path == 0) && !a.mask && !a.block_mask && a.dropout_p <= 0.0 && a.nq == a.nk && a.d <= 256 &&
+        !(backward ? bwd_mfma_supported(a.dtype, a.d) : fwd_mfma_supported(a.dtype, a.d))) {
+        if (!backward) return launch_fwd_generic(FwdArgs{a.q, a.k, a.v, a.o, a.lse, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale}, st);
+        return launch_bwd_generic(BwdArgs{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale,
+                                          a.workspace, ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
+    }
     // Nq != Nk without masks or dropout (cross attention; a cached prefix under the causal mask): the d = 128 kernels of the plain
     // path take separate row counts.  Under the causal mask only with Nk >= Nq: they assume that every query row sees key 0.
     if (plain && a.nq != a.nk && nqnk_mfma_supported(a.dtype, a.d, a.bh, a.nq, a.nk, a.causal)) {
