@@ -22,9 +22,28 @@ namespace fa {
 
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// rows r0 .. r0 + rows - 1 of a (n, d) matrix into an f32 LDS tile, zero-filled past n and d; `vec` (wave-uniform: d % 4 == 0 and
+// the tensor aligned for it): four elements per load (16 bytes of f32, 8 bytes of 16-bit elements) and one 16-byte LDS store
 template <typename T, int DP, int LD, int NTHREADS>
 __device__ __forceinline__ void ex_load_tile(float* __restrict__ dst, const T* __restrict__ src, int r0, int rows, int n,
-                                             int d) {
+                                             int d, bool vec) {
+    if (vec) {
+        for (int idx = threadIdx.x; idx < rows * (DP / 4); idx += NTHREADS) {
+            const int r = idx / (DP / 4), c = 4 * (idx - r * (DP / 4));
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + r < n && c < d) {
+                if constexpr (sizeof(T) == 4) {
+                    x = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + r) * d + c);
+                } else {
+                    T t[4];
+                    *reinterpret_cast<u32x2*>(t) = *reinterpret_cast<const u32x2*>(src + (size_t)(r0 + r) * d + c);
+                    x = f32x4{to_f32<T>(t[0]), to_f32<T>(t[1]), to_f32<T>(t[2]), to_f32<T>(t[3])};
+                }
+            }
+            *reinterpret_cast<f32x4*>(dst + r * LD + c) = x;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < rows * DP; idx += NTHREADS) {
         const int r = idx / DP, c = idx - r * DP;
         float x = 0.f;
@@ -32,6 +51,13 @@ __device__ __forceinline__ void ex_load_tile(float* __restrict__ dst, const T* _
         dst[r * LD + c] = x;
     }
 }
+template <typename T> __device__ __forceinline__ bool ex_quad_ok(int d, const void* a, const void* b, const void* c, const void* e) {
+    return d % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                           reinterpret_cast<uintptr_t>(e)) % (4 * sizeof(T))) == 0;
+}
+// Operand reads (as fa_generic.hip, round 2): the contraction index of the 16x16x4 MFMA is permuted so that a lane's operands for
+// four consecutive MFMAs are one 16-byte LDS read — lane (lr, lq), step j of super-step S: k = 16 S + 4 lq + j (A and B agree; the
+// sum stays an f32 fma chain).  The P / dS staging areas are wave-private: no workgroup barrier between writing and reading them.
 
 // ---- forward: one workgroup = NW waves = 16 NW query rows of one (b,h); key tiles of 32
 template <typename T, int DP, int NW>
@@ -51,7 +77,8 @@ __global__ __launch_bounds__(NW * 64) void ex_fwd_kernel(const T* __restrict__ q
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, q0, BM, p.nq, p.d);
+    const bool vec = ex_quad_ok<T>(p.d, q, k, v, q);
+    ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, q0, BM, p.nq, p.d, vec);
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -65,15 +92,20 @@ __global__ __launch_bounds__(NW * 64) void ex_fwd_kernel(const T* __restrict__ q
     for (int k0 = 0; k0 < kend; k0 += BN) {
         if (!ex_tile_live(p, q0, min(q0 + BM, p.nq), k0, min(k0 + BN, p.nk))) continue;   // block-sparse skip (uniform)
         __syncthreads();
-        ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BN, p.nk, p.d);
-        ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BN, p.nk, p.d);
+        ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BN, p.nk, p.d, vec);
+        ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BN, p.nk, p.d, vec);
         __syncthreads();
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int s = 0; s < DP / 4; ++s) {
-            const float a = Qs[(w * 16 + lr) * LD + 4 * s + lq];
-            s0 = MFMA_F32(a, Ks[lr * LD + 4 * s + lq], s0);
-            s1 = MFMA_F32(a, Ks[(16 + lr) * LD + 4 * s + lq], s1);
+#pragma unroll
+        for (int S = 0; S < DP / 16; ++S) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + (w * 16 + lr) * LD + 16 * S + 4 * lq);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ks + lr * LD + 16 * S + 4 * lq);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ks + (16 + lr) * LD + 16 * S + 4 * lq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0 = MFMA_F32(a[j], b0[j], s0);
+                s1 = MFMA_F32(a[j], b1[j], s1);
+            }
         }
         const int key0 = k0 + lr, key1 = k0 + 16 + lr;
 #pragma unroll
@@ -106,12 +138,13 @@ __global__ __launch_bounds__(NW * 64) void ex_fwd_kernel(const T* __restrict__ q
             Pw[(lq * 4 + i) * PLD + lr] = p0;
             Pw[(lq * 4 + i) * PLD + 16 + lr] = p1;
         }
-        __syncthreads();
 #pragma unroll
-        for (int s = 0; s < BN / 4; ++s) {
-            const float a = Pw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BN / 16; ++S) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Pw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Vs[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA_F32(a[j], Vs[(16 * S + 4 * lq + j) * LD + 16 * t + lr], acc[t]);
         }
     }
 #pragma unroll
@@ -167,8 +200,9 @@ __global__ __launch_bounds__(NW * 64) void ex_dkdv_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BK, p.nk, p.d);
-    ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BK, p.nk, p.d);
+    const bool vec = ex_quad_ok<T>(p.d, q, k, v, dout);
+    ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BK, p.nk, p.d, vec);
+    ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BK, p.nk, p.d, vec);
     f32x4 dka[NT], dva[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { dka[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -179,8 +213,8 @@ __global__ __launch_bounds__(NW * 64) void ex_dkdv_kernel(const T* __restrict__ 
     for (int r0 = qstart; r0 < p.nq; r0 += BQ) {
         if (!ex_tile_live(p, r0, min(r0 + BQ, p.nq), k0, min(k0 + BK, p.nk))) continue;
         __syncthreads();
-        ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, r0, BQ, p.nq, p.d);
-        ex_load_tile<T, DP, LD, NTH>(Os, dout + qbase, r0, BQ, p.nq, p.d);
+        ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, r0, BQ, p.nq, p.d, vec);
+        ex_load_tile<T, DP, LD, NTH>(Os, dout + qbase, r0, BQ, p.nq, p.d, vec);
         if (threadIdx.x < BQ) {
             const int r = r0 + threadIdx.x;
             Ls[threadIdx.x] = r < p.nq ? lse[(size_t)bh * p.nq + r] : 0.f;
@@ -190,10 +224,17 @@ __global__ __launch_bounds__(NW * 64) void ex_dkdv_kernel(const T* __restrict__ 
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int s = 0; s < DP / 4; ++s) {
-                st = MFMA_F32(Ks[(w * 16 + lr) * LD + 4 * s + lq], Qs[(qb * 16 + lr) * LD + 4 * s + lq], st);
-                dpt = MFMA_F32(Vs[(w * 16 + lr) * LD + 4 * s + lq], Os[(qb * 16 + lr) * LD + 4 * s + lq], dpt);
+#pragma unroll
+            for (int S = 0; S < DP / 16; ++S) {
+                const f32x4 ak = *reinterpret_cast<const f32x4*>(Ks + (w * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(Vs + (w * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(Qs + (qb * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bo = *reinterpret_cast<const f32x4*>(Os + (qb * 16 + lr) * LD + 16 * S + 4 * lq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st = MFMA_F32(ak[j], bq[j], st);
+                    dpt = MFMA_F32(av[j], bo[j], dpt);
+                }
             }
             const int row = r0 + qb * 16 + lr;   // query index (MFMA column)
             const float lq_ = Ls[qb * 16 + lr], dl_ = Ls[BQ + qb * 16 + lr];
@@ -206,16 +247,17 @@ __global__ __launch_bounds__(NW * 64) void ex_dkdv_kernel(const T* __restrict__ 
                 Sw[(lq * 4 + i) * PLD + qb * 16 + lr] = pr * (dpt[i] * ks_ - dl_);      // dS^T
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int s = 0; s < BQ / 4; ++s) {
-            const float ap = Pw[lr * PLD + 4 * s + lq];
-            const float as = Sw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BQ / 16; ++S) {
+            const f32x4 ap = *reinterpret_cast<const f32x4*>(Pw + lr * PLD + 16 * S + 4 * lq);
+            const f32x4 as = *reinterpret_cast<const f32x4*>(Sw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                dva[t] = MFMA_F32(ap, Os[(4 * s + lq) * LD + 16 * t + lr], dva[t]);
-                dka[t] = MFMA_F32(as, Qs[(4 * s + lq) * LD + 16 * t + lr], dka[t]);
-            }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dva[t] = MFMA_F32(ap[j], Os[(16 * S + 4 * lq + j) * LD + 16 * t + lr], dva[t]);
+                    dka[t] = MFMA_F32(as[j], Qs[(16 * S + 4 * lq + j) * LD + 16 * t + lr], dka[t]);
+                }
         }
     }
 #pragma unroll
@@ -254,8 +296,9 @@ __global__ __launch_bounds__(NW * 64) void ex_dq_kernel(const T* __restrict__ q,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
 
-    ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, q0, BM, p.nq, p.d);
-    ex_load_tile<T, DP, LD, NTH>(Os, dout + qbase, q0, BM, p.nq, p.d);
+    const bool vec = ex_quad_ok<T>(p.d, q, k, v, dout);
+    ex_load_tile<T, DP, LD, NTH>(Qs, q + qbase, q0, BM, p.nq, p.d, vec);
+    ex_load_tile<T, DP, LD, NTH>(Os, dout + qbase, q0, BM, p.nq, p.d, vec);
     float lrow[4], drow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -271,16 +314,23 @@ __global__ __launch_bounds__(NW * 64) void ex_dq_kernel(const T* __restrict__ q,
     for (int k0 = 0; k0 < kend; k0 += BN) {
         if (!ex_tile_live(p, q0, min(q0 + BM, p.nq), k0, min(k0 + BN, p.nk))) continue;
         __syncthreads();
-        ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BN, p.nk, p.d);
-        ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BN, p.nk, p.d);
+        ex_load_tile<T, DP, LD, NTH>(Ks, k + kbase, k0, BN, p.nk, p.d, vec);
+        ex_load_tile<T, DP, LD, NTH>(Vs, v + kbase, k0, BN, p.nk, p.d, vec);
         __syncthreads();
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int ks = 0; ks < DP / 4; ++ks) {
-                s = MFMA_F32(Qs[(w * 16 + lr) * LD + 4 * ks + lq], Ks[(nb * 16 + lr) * LD + 4 * ks + lq], s);
-                dp = MFMA_F32(Os[(w * 16 + lr) * LD + 4 * ks + lq], Vs[(nb * 16 + lr) * LD + 4 * ks + lq], dp);
+#pragma unroll
+            for (int S = 0; S < DP / 16; ++S) {
+                const f32x4 aq = *reinterpret_cast<const f32x4*>(Qs + (w * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 ao = *reinterpret_cast<const f32x4*>(Os + (w * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bk = *reinterpret_cast<const f32x4*>(Ks + (nb * 16 + lr) * LD + 16 * S + 4 * lq);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(Vs + (nb * 16 + lr) * LD + 16 * S + 4 * lq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s = MFMA_F32(aq[j], bk[j], s);
+                    dp = MFMA_F32(ao[j], bv[j], dp);
+                }
             }
             const int key = k0 + nb * 16 + lr;
 #pragma unroll
@@ -291,12 +341,13 @@ __global__ __launch_bounds__(NW * 64) void ex_dq_kernel(const T* __restrict__ q,
                 Sw[(lq * 4 + i) * PLD + nb * 16 + lr] = pr * (dp[i] * ks_ - drow[i]);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int s = 0; s < BN / 4; ++s) {
-            const float a = Sw[lr * PLD + 4 * s + lq];
+        for (int S = 0; S < BN / 16; ++S) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Sw + lr * PLD + 16 * S + 4 * lq);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA_F32(a, Ks[(4 * s + lq) * LD + 16 * t + lr], acc[t]);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = MFMA_F32(a[j], Ks[(16 * S + 4 * lq + j) * LD + 16 * t + lr], acc[t]);
         }
     }
 #pragma unroll
