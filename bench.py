@@ -271,6 +271,9 @@ def main(argv=None):
                 gbps = dq_bytes / (ms_ / c_ * 1e-3) / 1e9
                 per_kernel["bwd_dq_mfma"].update({"bound": "hbm", "algorithmic_bytes_per_launch": dq_bytes, "achieved_GBps": round(gbps, 1),
                                                   "peak_GBps": 8000.0, "frac": round(gbps / 8000.0, 4)})
+                # the dK/dV kernel's algorithmic bytes with the hand-over: q, k, v, dO in, dK, dV out, row constants, and the dS tiles
+                # it writes for the dQ kernel (compare with hbm_bytes: measured traffic per launch)
+                per_kernel["bwd_mfma"]["algorithmic_bytes_per_launch"] = bh * (6 * N * D * 2.0 + 8.0 * N + N * N * 2.0 * vis) / launches_per_step
             bwd_ms = sum(ms_ / c_ for kname, (c_, ms_) in prof.items() if kname.startswith("bwd"))
             all_ms = sum(ms_ / c_ for kname, (c_, ms_) in prof.items())
             roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
