@@ -301,11 +301,12 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
 
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st) {
     // d = 128: the one-wave-per-SIMD stream kernel (fa_bwd_dkdv_w4.hip) is the default (-13 % non-causal, -8 ... -10 %
-    // causal against the 8-wave kernel below, profiles/r02_dkdv_stream.md); small launches keep the 128-key tiles.
+    // causal against the 8-wave kernel below, profiles/r02_dkdv_stream.md); small CAUSAL launches keep the 128-key tiles (without
+    // the mask the stream kernel wins at every size: profiles/r02_small_launches.md).
     // Option dkdv: 5 = always the stream kernel, 8 = the 8-wave kernel.
     const int dk_opt = option(OPT_DKDV);
     const bool sweeping = option(OPT_DKDV_KREG) || option(OPT_DKDV_TPW) || option(OPT_DKDV_STG);
-    if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && !small_grid(a.bh, a.n))))
+    if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && (!small_grid(a.bh, a.n, true) || !a.causal))))
         return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dkdv_t<bf16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 256, true>(a, nlse, ndelta, st);
@@ -315,7 +316,7 @@ hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float
         if (a.dtype == 2) return a.d > 64 ? launch_dkdv_t<bf16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, true>(a, nlse, ndelta, st);
         return a.d > 64 ? launch_dkdv_t<f16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, true>(a, nlse, ndelta, st);
     }
-    if (option(OPT_DKDV_KREG) == 0 && option(OPT_DKDV_TPW) == 0 && small_grid(a.bh, a.n)) {   // 128-key tiles on 4 waves
+    if (option(OPT_DKDV_KREG) == 0 && option(OPT_DKDV_TPW) == 0 && small_grid(a.bh, a.n, true)) {   // 128-key tiles on 4 waves
         if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, false, true>(a, nlse, ndelta, st);
         return a.d == 128 ? launch_dkdv_t<f16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, false, true>(a, nlse, ndelta, st);
     }

@@ -269,7 +269,7 @@ static hipError_t launch_dq_kt(const BwdArgs& a, float* nlse, float* ndelta, hip
 // option dq_kt=2 selects two 64-key sub-tiles per barrier (sweep)
 template <typename Tag, int D>
 static hipError_t launch_dq_t(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st) {
-    if (option(OPT_DQ_W4) == 1 || (option(OPT_DQ_W4) == 0 && option(OPT_DQ_KT) == 0 && option(OPT_DQ_TPW) == 0 && small_grid(a.bh, a.n)))
+    if (option(OPT_DQ_W4) == 1 || (option(OPT_DQ_W4) == 0 && option(OPT_DQ_KT) == 0 && option(OPT_DQ_TPW) == 0 && small_grid(a.bh, a.n, true)))
         return launch_dq_kt<Tag, D, 1, false, true>(a, nlse, ndelta, st);
     return option(OPT_DQ_KT) == 2 ? launch_dq_kt<Tag, D, 2>(a, nlse, ndelta, st) : launch_dq_kt<Tag, D, 1>(a, nlse, ndelta, st);
 }
@@ -280,7 +280,7 @@ hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipS
     // Option dq: 5 = always the stream kernel, 8 = the 8-wave kernel.
     const int dq_opt = option(OPT_DQ);
     const bool sweeping = option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || option(OPT_DQ_W4);
-    if (bwd_dq_w4_supported(a.dtype, a.d) && (dq_opt == 5 || (dq_opt == 0 && !sweeping && !small_grid(a.bh, a.n))))
+    if (bwd_dq_w4_supported(a.dtype, a.d) && (dq_opt == 5 || (dq_opt == 0 && !sweeping && (!small_grid(a.bh, a.n, true) || !a.causal))))
         return launch_bwd_dq_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dq_kt<bf16_tag, 256, 1, false>(a, nlse, ndelta, st) : launch_dq_kt<bf16_tag, 256, 1, true>(a, nlse, ndelta, st);

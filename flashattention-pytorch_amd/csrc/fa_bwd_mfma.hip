@@ -366,7 +366,7 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
     (void)causal;   // (under the mask half of every (b,h)'s tile grid stays unwritten and unread: the layout is the same)
-    return dq_opt == 6 || !small_grid(bh, n);
+    return dq_opt == 6 || !small_grid(bh, n, true);   // (up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead)
 }
 static int64_t ds_chunk_units(int64_t bh, int64_t n) {
     const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));

@@ -752,12 +752,16 @@ static hipError_t launch_fwd_w4(const FwdArgs& a, hipStream_t st) {
                     : launch(fwd_mfma_kernel<Tag, D, false, KB, false, true, false, 1, false, 0, true>);
 }
 
-// does the launch leave CUs without a workgroup when tiled by 256 rows?  (option small_grid: 1 = never, 2 = always)
-bool small_grid(int64_t bh, int64_t n) {
+// Is the launch better served by the 4-wave / 128-row kernels than by 256-row tiles?  (option small_grid: 1 = never, 2 = always.)
+// Measured at d = 128, bh x N from 12 x 2048 to 24 x 8192 (profiles/r02_small_launches.md): the forward while its 128-row
+// workgroups still fit the chip in ONE round (<= 128 tiles of 256 rows: 0.051 vs 0.058 ms at 16 x 2048; with 160 tiles the second
+// round costs 0.099 vs 0.060); the causal backward up to 256 tiles (0.550 vs 0.612 ms at 8 x 8192; 0.887 vs 0.702 at 12 x 8192).
+// The non-causal backward does not ask: the stream kernels win at every size there (0.264 vs 0.388 ms at 8 x 4096).
+bool small_grid(int64_t bh, int64_t n, bool backward) {
     const int o = option(OPT_SMALL_GRID);
     if (o == 1) return false;
     if (o == 2) return true;
-    return bh * ((n + 255) / 256) < 224;
+    return bh * ((n + 255) / 256) <= (backward ? 256 : 128);
 }
 
 template <typename Tag, int D>
@@ -777,7 +781,7 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
 }
 
 bool nqnk_mfma_supported(int dtype, int64_t d, int64_t bh, int64_t nq, int64_t nk, int causal) {
-    return (dtype == 1 || dtype == 2) && d == 128 && nq > 0 && nk > 0 && (!causal || nk >= nq) && !small_grid(bh, nq < nk ? nq : nk);
+    return (dtype == 1 || dtype == 2) && d == 128 && nq > 0 && nk > 0 && (!causal || nk >= nq) && !small_grid(bh, nq < nk ? nq : nk, false);
 }
 hipError_t launch_fwd_nqnk(const FwdArgs& a, hipStream_t st) {   // the staggered kernel, 128-key tiles, with a.nk keys
     return a.dtype == 2 ? launch_fwd_t<bf16_tag, 128, 4>(a, st, true) : launch_fwd_t<f16_tag, 128, 4>(a, st, true);
@@ -790,13 +794,13 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
     }
     if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
         // 128-wide tiles: the staggered kernel, as for d = 128 (fwd_stag = 2: lock step); 64-wide: lock step
-        const bool stag = a.d > 64 && option(OPT_FWD_STAG) != 2 && !small_grid(a.bh, a.n);
+        const bool stag = a.d > 64 && option(OPT_FWD_STAG) != 2 && !small_grid(a.bh, a.n, false);
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
     }
     const bool sweeping = option(OPT_FWD_KB) || (option(OPT_FWD_STAG) & 1) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
                           option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
-    if (!sweeping && small_grid(a.bh, a.n)) {
+    if (!sweeping && small_grid(a.bh, a.n, false)) {
         if (a.dtype == 2) return a.d == 128 ? launch_fwd_w4<bf16_tag, 128>(a, st) : launch_fwd_w4<bf16_tag, 64>(a, st);
         return a.d == 128 ? launch_fwd_w4<f16_tag, 128>(a, st) : launch_fwd_w4<f16_tag, 64>(a, st);
     }

@@ -49,13 +49,14 @@ def test_workspace_query_and_argument_validation_without_gpu():
     assert lib.fa_backward_workspace_bytes(4, 128, 64, 2) >= 4 * 128 * 4
     assert lib.fa_backward_workspace_bytes(0, 0, 64, 2) > 0
     # the dS hand-over's size: N * N * 2 bytes per (b,h) on top of the minimum where it serves the call (d = 128, 16-bit, no
-    # launch of >= 224 row tiles), at most 16 GiB (equal chunks of (b,h) units); the minimum everywhere else
+    # launch of > 256 row tiles), at most 16 GiB (equal chunks of (b,h) units); the minimum everywhere else
     base = lib.fa_backward_workspace_bytes(256, 4096, 128, 2)
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 0) == base + 256 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 1) == base + 256 * 4096 * 4096 * 2   # the same under the mask
     assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 512 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(600, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(600, 4096, 128, 1) + 300 * 4096 * 4096 * 2   # 2 x 300, not 512 + 88
-    assert lib.fa_backward_workspace_bytes_fast(64, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 1000, 128, 2) + 64 * 32 * 32 * 2048  # ragged N: whole tiles
+    assert lib.fa_backward_workspace_bytes_fast(80, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(80, 1000, 128, 2) + 80 * 32 * 32 * 2048  # ragged N: whole tiles
+    assert lib.fa_backward_workspace_bytes_fast(64, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 1000, 128, 2)  # 256 tiles of 256 rows: still the recomputing pass
     assert lib.fa_backward_workspace_bytes_fast(2, 512, 128, 2, 0) == lib.fa_backward_workspace_bytes(2, 512, 128, 2)     # small launch
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 64, 2, 0) == lib.fa_backward_workspace_bytes(256, 4096, 64, 2)  # d = 64
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 0, 0) == lib.fa_backward_workspace_bytes(256, 4096, 128, 0)  # fp32

@@ -94,7 +94,7 @@ def test_workspace_sizes_are_the_tile_grid():
     import flashattention_lab_cuda as ext
 
     lib = ext._lib
-    for bh, n in ((256, 4096), (64, 1000), (128, 8192), (300, 4100)):
+    for bh, n in ((256, 4096), (80, 1000), (128, 8192), (300, 4100)):
         tiles = ((n + 31) // 32) * (8 * ((n + 255) // 256))          # 32-query blocks x 32-key blocks (keys padded to 256-key tiles)
         per_unit = tiles * 2048
         fit = (16 << 30) // per_unit

@@ -17,9 +17,9 @@ def _cases(count, seed):
     out = []
     for i in range(count):
         d = rng.choice([8, 16, 24, 40, 48, 64, 64, 72, 96, 104, 128, 128, 128, 136, 192, 256])
-        if i % 5 == 4:   # a launch large enough for the 8-wave kernels: bh * ceil(n / 256) >= 224
+        if i % 5 == 4:   # a launch large enough for the 256-row kernels in both directions: bh * ceil(n / 256) > 256
             n = rng.choice([257, 300, 511, 512, 700])
-            bh = 224 // ((n + 255) // 256) + rng.randint(1, 6)
+            bh = 256 // ((n + 255) // 256) + rng.randint(1, 6)
             d = rng.choice([40, 64, 96, 128, 256])
         else:
             n = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 513, 767, 769, 1023, 1025, 1300])

@@ -685,7 +685,7 @@ DS_SHAPES = [(2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("rows", [512, 256])
 def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device):
-    """Option dq = 6 forces the path on launches of any size (its default is launches of >= 224 row tiles); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
+    """Option dq = 6 forces the path on launches of any size (its default is launches of > 256 row tiles); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
     (ds_chunk_mb), so the chunk loop runs too."""
     import flashattention_lab_cuda as ext
 
