@@ -757,11 +757,12 @@ static hipError_t launch_fwd_w4(const FwdArgs& a, hipStream_t st) {
 // workgroups still fit the chip in ONE round (<= 128 tiles of 256 rows: 0.051 vs 0.058 ms at 16 x 2048; with 160 tiles the second
 // round costs 0.099 vs 0.060); the causal backward up to 256 tiles (0.550 vs 0.612 ms at 8 x 8192; 0.887 vs 0.702 at 12 x 8192).
 // The non-causal backward does not ask: the stream kernels win at every size there (0.264 vs 0.388 ms at 8 x 4096).
-bool small_grid(int64_t bh, int64_t n, bool backward) {
+// 64-wide tiles (d <= 64): the forward's 4-wave kernel stays ahead up to 256 tiles (0.043 vs 0.068 ms at 32 x 2048).
+bool small_grid(int64_t bh, int64_t n, bool backward, int64_t d) {
     const int o = option(OPT_SMALL_GRID);
     if (o == 1) return false;
     if (o == 2) return true;
-    return bh * ((n + 255) / 256) <= (backward ? 256 : 128);
+    return bh * ((n + 255) / 256) <= ((backward || d <= 64) ? 256 : 128);
 }
 
 template <typename Tag, int D>
@@ -781,7 +782,7 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
 }
 
 bool nqnk_mfma_supported(int dtype, int64_t d, int64_t bh, int64_t nq, int64_t nk, int causal) {
-    return (dtype == 1 || dtype == 2) && d == 128 && nq > 0 && nk > 0 && (!causal || nk >= nq) && !small_grid(bh, nq < nk ? nq : nk, false);
+    return (dtype == 1 || dtype == 2) && d == 128 && nq > 0 && nk > 0 && (!causal || nk >= nq) && !small_grid(bh, nq < nk ? nq : nk, false, d);
 }
 hipError_t launch_fwd_nqnk(const FwdArgs& a, hipStream_t st) {   // the staggered kernel, 128-key tiles, with a.nk keys
     return a.dtype == 2 ? launch_fwd_t<bf16_tag, 128, 4>(a, st, true) : launch_fwd_t<f16_tag, 128, 4>(a, st, true);
@@ -794,13 +795,13 @@ hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st) {
     }
     if (a.d != 64 && a.d != 128) {   // head dims 8, 16, ... below the tile width: zero-padded inside the kernel
         // 128-wide tiles: the staggered kernel, as for d = 128 (fwd_stag = 2: lock step); 64-wide: lock step
-        const bool stag = a.d > 64 && option(OPT_FWD_STAG) != 2 && !small_grid(a.bh, a.n, false);
+        const bool stag = a.d > 64 && option(OPT_FWD_STAG) != 2 && !small_grid(a.bh, a.n, false, a.d);
         if (a.dtype == 2) return a.d > 64 ? launch_fwd_t<bf16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<bf16_tag, 64, 4, true>(a, st);
         return a.d > 64 ? launch_fwd_t<f16_tag, 128, 4, true>(a, st, stag) : launch_fwd_t<f16_tag, 64, 4, true>(a, st);
     }
     const bool sweeping = option(OPT_FWD_KB) || (option(OPT_FWD_STAG) & 1) || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) ||
                           option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
-    if (!sweeping && small_grid(a.bh, a.n, false)) {
+    if (!sweeping && small_grid(a.bh, a.n, false, a.d)) {
         if (a.dtype == 2) return a.d == 128 ? launch_fwd_w4<bf16_tag, 128>(a, st) : launch_fwd_w4<bf16_tag, 64>(a, st);
         return a.d == 128 ? launch_fwd_w4<f16_tag, 128>(a, st) : launch_fwd_w4<f16_tag, 64>(a, st);
     }

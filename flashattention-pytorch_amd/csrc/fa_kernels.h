@@ -61,7 +61,7 @@ size_t bwd_generic_workspace_bytes(int64_t bh, int64_t n);
 
 // 16-bit MFMA kernels (fa_fwd_mfma.hip / fa_bwd_mfma.hip): f16/bf16, d in {64, 128}
 bool fwd_mfma_supported(int dtype, int64_t d);
-bool small_grid(int64_t bh, int64_t n, bool backward);   // the 4-wave / 128-row kernels serve the launch better than 256-row tiles
+bool small_grid(int64_t bh, int64_t n, bool backward, int64_t d = 128);   // the 4-wave / 128-row kernels serve the launch better than 256-row tiles
 hipError_t set_trace_buffer(void* device_ptr);   // debug: phase timestamps of the staggered forward (fa_fwd_mfma.hip)
 hipError_t launch_fwd_mfma(const FwdArgs& a, hipStream_t st);
 // Nq != Nk on the plain path's d = 128 kernels (staggered forward, stream backward): 16-bit tensors, Nk % 64 == 0 not needed,
