@@ -642,6 +642,35 @@ def test_forward_backward_capture_into_a_hip_graph(device):
         assert torch.equal(a, b)
 
 
+def test_ds_handover_backward_captures_into_a_hip_graph(device):
+    """The same for a launch the dS hand-over serves by default (320 row tiles): preparation launch, dK/dV kernel with its dS
+    stores and the dQ product kernel are plain launches on the caller's stream, the workspace comes from the capturing allocator."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 80, 1000, 128
+    q, k, v, do = (t.to(device) for t in make_qkv(bh, n, d, torch.bfloat16, seed=13))
+    o, lse = ext.forward(q, k, v, False, d ** -0.5, 64, 128)
+    ext.profile_enable(True)
+    ref_g = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    assert "bwd_delta" in ext.profile_report()          # the hand-over ran (only it has the preparation launch at d = 128)
+    ext.profile_enable(False)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dq, dk, dv = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    for _ in range(2):
+        dq.zero_(); dk.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    for x, y in zip((dq, dk, dv), ref_g):
+        assert torch.equal(x, y)
+
+
 def test_extreme_inputs_stay_finite_and_match(device):
     """Large-magnitude scores (|s| ~ 1e3 after scaling), a tiny softmax_scale and N=1: no overflow / NaN, and the result
     still matches the fp64 oracle at the reference's tolerance."""
