@@ -365,8 +365,12 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
-    (void)causal;   // (under the mask half of every (b,h)'s tile grid stays unwritten and unread: the layout is the same)
-    return dq_opt == 6 || !small_grid(bh, n, true);   // (up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead)
+    // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead; under the causal mask (half of every (b,h)'s
+    // tile grid stays unwritten and unread, the stores cost the dK/dV kernel 10 %) up to about 768: 16 x 8192 0.75 vs 0.80 ms,
+    // 32 x 4096 0.43 vs 0.46, but 24 x 8192 1.36 vs 1.29, 48 x 4096 0.78 vs 0.77, 256 x 4096 -2.6 % per step (profiles/r02_ds_handover.md).
+    if (dq_opt == 6) return true;
+    if (small_grid(bh, n, true)) return false;
+    return !causal || option(OPT_SMALL_GRID) == 1 || bh * ((n + 255) / 256) >= 768;
 }
 static int64_t ds_chunk_units(int64_t bh, int64_t n) {
     const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));

@@ -53,6 +53,8 @@ def test_workspace_query_and_argument_validation_without_gpu():
     base = lib.fa_backward_workspace_bytes(256, 4096, 128, 2)
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 0) == base + 256 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 1) == base + 256 * 4096 * 4096 * 2   # the same under the mask
+    assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 1) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2)   # ... from 768 tiles on
+    assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 0) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2) + 32 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 512 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(600, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(600, 4096, 128, 1) + 300 * 4096 * 4096 * 2   # 2 x 300, not 512 + 88
     assert lib.fa_backward_workspace_bytes_fast(80, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(80, 1000, 128, 2) + 80 * 32 * 32 * 2048  # ragged N: whole tiles
