@@ -773,7 +773,12 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     // same order).  Option fwd_stag: 1 = staggered with 64-key tiles, 2 = lock step, 3 = staggered with 128-key tiles.
     const int so = option(OPT_FWD_STAG);
     const bool other_sweep = kb || option(OPT_FWD_RS) || option(OPT_FWD_EAGER) || option(OPT_FWD_HS) || option(OPT_FWD_TPW) || option(OPT_FWD_ABL);
-    if ((D == 128 && (so == 3 || (so == 0 && !other_sweep))) || (D == 64 && so == 3)) return launch_fwd_t<Tag, D, 4>(a, st, true);
+    // Under the causal mask the staggered kernel (one tile per workgroup, heaviest first) pays only on long rows: the lock-step
+    // kernel with its heavy + light tile pairs is ahead by 15 - 27 % at N = 1024, 5 - 25 % at N = 2048, 3 - 10 % at N = 4096 below
+    // about 3000 row tiles, and behind by 3 - 6 % from there on (256 x 4096, N >= 8192: profiles/r02_small_launches.md §5).
+    // Without the mask the two are level at N = 1024 and the lock-step kernel is 8 - 10 % ahead at N = 512.
+    const bool short_rows = a.causal ? !(a.n >= 8192 || (a.n >= 4096 && a.bh * ((a.n + 255) / 256) >= 3072)) : a.n < 1024;
+    if ((D == 128 && (so == 3 || (so == 0 && !other_sweep && !short_rows))) || (D == 64 && so == 3)) return launch_fwd_t<Tag, D, 4>(a, st, true);
     const bool stag = D == 128 && so == 1;
     if (stag) return launch_fwd_t<Tag, D, 2>(a, st, true);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
