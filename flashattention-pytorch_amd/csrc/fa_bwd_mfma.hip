@@ -370,6 +370,7 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     // 32 x 4096 0.43 vs 0.46, but 24 x 8192 1.36 vs 1.29, 48 x 4096 0.78 vs 0.77, 256 x 4096 -2.6 % per step (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
     if (small_grid(bh, n, true)) return false;
+    if (causal && n <= 1024) return false;   // (there the 8-wave dK/dV kernel is the default: launch_bwd_dkdv_mfma)
     return !causal || option(OPT_SMALL_GRID) == 1 || bh * ((n + 255) / 256) >= 768;
 }
 static int64_t ds_chunk_units(int64_t bh, int64_t n) {
