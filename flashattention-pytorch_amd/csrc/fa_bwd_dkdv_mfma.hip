@@ -285,8 +285,10 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
         return hipGetLastError();
     };
     if constexpr (D == 64 && !PAD && !W4) {
-        if (option(OPT_DKDV_KREG) != 0)
+        if (option(OPT_DKDV_KREG) != 0) {
+            grid = dim3((unsigned)(nkt * a.bh));   // (one tile per workgroup: the variant has no pairing; until round 2 the causal sweep ran it on half a grid)
             return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1, PAD, W4>);
+        }
     }
     if (tpw == 2)
         return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, false, 2, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, false, 2, PAD, W4>);

@@ -783,6 +783,10 @@ static hipError_t launch_fwd_kb(const FwdArgs& a, hipStream_t st) {
     if (stag) return launch_fwd_t<Tag, D, 2>(a, st, true);
     if (kb == 1 && D == 128) return launch_fwd_t<Tag, D, (D == 128 ? 1 : 2)>(a, st);
     if (kb == 2) return launch_fwd_t<Tag, D, 2>(a, st);
+    // 64-wide tiles without the mask: 64-key K/V tiles, one query tile per workgroup (re-measured in round 2: 4 - 9 % ahead of
+    // 128-key tiles with two query tiles per workgroup, 128 x 2048 ... 64 x 8192; under the mask the pairing of heavy and light tiles
+    // — which needs the 128-key form — stays ahead except on the longest launches)
+    if (D == 64 && kb == 0 && !a.causal && !other_sweep) return launch_fwd_t<Tag, D, 2>(a, st);
     return launch_fwd_t<Tag, D, 4>(a, st);   // 128-key tiles: fewest barriers per key (LDS 128 KiB at d = 128)
 }
 
