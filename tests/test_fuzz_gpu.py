@@ -21,6 +21,10 @@ def _cases(count, seed):
             n = rng.choice([257, 300, 511, 512, 700])
             bh = 256 // ((n + 255) // 256) + rng.randint(1, 6)
             d = rng.choice([40, 64, 96, 128, 256])
+        elif i % 7 == 6:   # around the limits of the kernel-choice rules: 100 .. 900 tiles of 256 rows, rows of 1000 .. 4500
+            n = rng.choice([1000, 1024, 1025, 1500, 2048, 3000, 4096, 4500])
+            bh = max(1, rng.choice([100, 130, 200, 256, 260, 400, 760, 770, 900]) // ((n + 255) // 256))
+            d = rng.choice([64, 128, 128, 128])
         else:
             n = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 513, 767, 769, 1023, 1025, 1300])
             bh = rng.randint(1, 5)
