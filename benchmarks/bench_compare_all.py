@@ -15,23 +15,41 @@ from bench_utils import (DTYPES, BenchmarkRecord, add_common_args, algorithmic_t
                          format_table, has_hip_extension, is_oom_error, iter_causal_flags, make_qkv, write_results)
 
 
-def main(argv=None):
+def build_parser(default_tag="compare_all"):
+    """The reference's flags, one for one (bench_compare_all.py:70-91, bench_fa3.py:50-70): the figure / table flags
+    (--config-label, --plot-dtype, --no-plot, --caption) are accepted so that a reference command line runs unchanged;
+    --config-label lands in the records' `config` field as it does there, the other three only matter to the plotting
+    this repo does not rebuild (cosmetic).  --algos / --no-save are this repo's additions."""
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     add_common_args(ap)
+    ap.add_argument("--fp8", action="store_true", help="Include fp8 path for FA3")
+    ap.add_argument("--directions", nargs="+", default=["forward"], choices=["forward", "backward"],
+                    help="Benchmark forward, backward, or both (default: forward, as the reference)")
+    ap.add_argument("--tag", type=str, default=default_tag, help="Base name for result files")
+    ap.add_argument("--config-label", type=str, default=None, help="Optional config name for tables (the records' config field)")
+    ap.add_argument("--plot-dtype", type=str, default=None, help="accepted for compatibility: no figures are made here")
+    ap.add_argument("--no-plot", action="store_true", help="accepted for compatibility: no figures are made here")
+    ap.add_argument("--caption", type=str, default="Figure 6: Attention backward speed (FP16/BF16) on H100 GPU.",
+                    help="accepted for compatibility: no figures are made here")
     ap.add_argument("--algos", nargs="+", default=["fa1", "fa2", "fa3"], choices=["fa1", "fa2", "fa3"])
-    ap.add_argument("--directions", nargs="+", default=["forward", "backward"], choices=["forward", "backward"])
-    ap.add_argument("--fp8", action="store_true", help="FA3: also run fp8=True")
-    ap.add_argument("--tag", default="compare_all")
     ap.add_argument("--no-save", action="store_true")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def main(argv=None, default_tag="compare_all"):
+    args = build_parser(default_tag).parse_args(argv)
+    # The reference runs its torch backend on --device cpu; this build has no CPU compute path (DESIGN.md §1): every sweep
+    # point is then recorded as an error, the table is still printed, and the exit code says so.
+    no_backend = None
     if args.device != "cuda" or not has_hip_extension():
-        sys.exit("the MI355X build has no CPU backend: run on a GPU box with the library built (make -C flashattention-pytorch_amd/csrc)")
+        no_backend = "the MI355X build has no CPU backend: run on a GPU box with the library built (make -C flashattention-pytorch_amd/csrc)"
+    ops = {}
+    if no_backend is None:
+        from fa1.op import fa1_attention
+        from fa2.op import fa2_attention
+        from fa3.op import fa3_attention
 
-    from fa1.op import fa1_attention
-    from fa2.op import fa2_attention
-    from fa3.op import fa3_attention
-
-    ops = {"fa1": fa1_attention, "fa2": fa2_attention, "fa3": fa3_attention}
+        ops = {"fa1": fa1_attention, "fa2": fa2_attention, "fa3": fa3_attention}
     records = []
     for direction in args.directions:
         for n in args.seqlen:
@@ -42,11 +60,20 @@ def main(argv=None):
                             for dt in args.dtypes:
                                 for algo in args.algos:
                                     for fp8 in ([False, True] if (algo == "fa3" and args.fp8) else [False]):
-                                        records.append(run_one(ops[algo], algo, direction, n, d, b, h, causal, dt, fp8, args))
+                                        if no_backend is not None:
+                                            records.append(BenchmarkRecord(
+                                                method=algo.upper(), algo=algo, backend="cuda", direction=direction, dtype=dt, causal=causal,
+                                                seqlen=n, head_dim=d, batch_size=b, num_heads=h, mean_ms=None, std_ms=None, tflops=None,
+                                                peak_mem_mb=None, status="error", fp8=fp8 if algo == "fa3" else None,
+                                                config=args.config_label, error=no_backend))
+                                        else:
+                                            records.append(run_one(ops[algo], algo, direction, n, d, b, h, causal, dt, fp8, args))
     headers = ["method", "backend", "direction", "dtype", "shape", "mask", "mean ms", "std ms", "TFLOP/s (ref conv.)", "mem MB", "status"]
     print(format_table(headers, [r.to_row() for r in records]))
     if not args.no_save:
         print(write_results(args.tag, records))
+    if no_backend is not None:
+        sys.exit(no_backend)
     return records
 
 
@@ -71,11 +98,12 @@ def run_one(op, algo, direction, n, d, b, h, causal, dt, fp8, args):
                 return out
         mean, std, mem = benchmark_fn(call, "cuda", args.warmup, args.iters)
         return BenchmarkRecord(mean_ms=mean, std_ms=std, tflops=compute_tflops(b, h, n, d, mean, direction), peak_mem_mb=mem,
-                               status="ok", config=f"algorithmic {algorithmic_tflops(b, h, n, d, mean, direction, causal):.1f} TFLOP/s", **rec)
+                               status="ok", config=args.config_label if args.config_label is not None else
+                               f"algorithmic {algorithmic_tflops(b, h, n, d, mean, direction, causal):.1f} TFLOP/s", **rec)
     except Exception as exc:  # noqa: BLE001 - a sweep records the failure and moves on (bench_fa2.py:136-139)
         torch.cuda.empty_cache()
         return BenchmarkRecord(mean_ms=None, std_ms=None, tflops=None, peak_mem_mb=None,
-                               status="oom" if is_oom_error(exc) else "error", error=str(exc)[:200], **rec)
+                               status="oom" if is_oom_error(exc) else "error", config=args.config_label, error=str(exc)[:200], **rec)
 
 
 if __name__ == "__main__":

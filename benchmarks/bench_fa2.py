@@ -9,7 +9,4 @@ import sys
 import bench_compare_all
 
 if __name__ == "__main__":
-    argv = sys.argv[1:]
-    if "--tag" not in argv:
-        argv += ["--tag", "fa2"]
-    bench_compare_all.main(["--algos", "fa2"] + argv)
+    bench_compare_all.main(["--algos", "fa2"] + sys.argv[1:], default_tag="fa2")

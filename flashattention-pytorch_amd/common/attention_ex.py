@@ -27,6 +27,30 @@ def look_ahead_mask(q_len, k_len=None, device=None):
     return (kj <= qi + (k_len - q_len)).unsqueeze(0).unsqueeze(0)
 
 
+def normalize_mask(mask, lead, nq, nk):
+    """The model's `mask` (True / non-zero = allowed), "broadcastable to (B, H, Nq, Nk)" as the reference uses it
+    (`scores.masked_fill(mask[:, :, i0:i1, j0:j1] == 0, -inf)`, flashattention_pytorch.py:139-141: ordinary broadcasting against
+    the (B, H, Br, Bc) scores), in one of the two forms the library takes: (Nq, Nk) when every leading dim is 1 — one mask
+    shared by all (b,h) — else (BH, Nq, Nk).  `lead` = q's leading dims, (B, H) or (BH,).  A key-padding mask (B, 1, 1, Nk)
+    or (1, 1, 1, Nk) is expanded over the query rows like any other broadcast dim."""
+    m = mask != 0
+    if m.dim() > len(lead) + 2:
+        if all(s == 1 for s in m.shape[: m.dim() - 2]):
+            m = m.reshape(m.shape[-2:])
+        elif len(lead) == 1 and math.prod(m.shape[:-2]) == lead[0]:
+            m = m.reshape(lead[0], *m.shape[-2:])      # a (B, H, ., .) mask with already merged (BH, N, d) tensors
+        else:
+            raise RuntimeError(f"mask of shape {tuple(mask.shape)} does not broadcast to {(*lead, nq, nk)}")
+    while m.dim() < len(lead) + 2:
+        m = m.unsqueeze(0)
+    shared = all(s == 1 for s in m.shape[:-2])
+    try:
+        m = torch.broadcast_to(m, ((1,) * len(lead) if shared else lead) + (nq, nk))
+    except RuntimeError as exc:
+        raise RuntimeError(f"mask of shape {tuple(mask.shape)} does not broadcast to {(*lead, nq, nk)}") from exc
+    return m.reshape(nq, nk) if shared else m.reshape(-1, nq, nk)
+
+
 class _FlashAttnExFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, causal, scale, mask, block_mask, br, bc, dropout_p, seed):
@@ -62,13 +86,7 @@ def flash_attention_ex(q, k, v, tau=1.0, mask=None, block_sparse_mask=None, bloc
     scale = (tau / math.sqrt(d)) if softmax_scale is None else float(softmax_scale) * tau   # :134
     m = None
     if mask is not None:
-        m = mask != 0
-        if m.dim() == 2:
-            pass                                  # (Nq, Nk): shared
-        elif all(s == 1 for s in m.shape[:-2]):
-            m = m.reshape(nq, nk)                 # (1, 1, Nq, Nk): shared
-        else:                                     # per batch and / or head: one mask per (b,h)
-            m = m.expand(*q.shape[:-2], nq, nk).reshape(-1, nq, nk)
+        m = normalize_mask(mask, tuple(q.shape[:-2]), nq, nk)
     br = bc = int(block_size)
     if block_sparse_mask is not None:
         br, bc = min(br, nq), min(bc, nk)         # Br = min(block_size, q_len), Bc = min(block_size, kv_len)  (:100-101)

@@ -349,14 +349,19 @@ bool bwd_mfma_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2
 
 // workspace: [nlse (bh*n)] [ndelta (bh*n)] [pad to 256 B] [dq scratch fp32 (bh*n*d): single-kernel (atomic) variant only]
 static size_t row_constants_bytes(int64_t bh, int64_t n) { return (sizeof(float) * 2 * (size_t)bh * n + 255) & ~(size_t)255; }
-// The dS hand-over (d = 128, launches big enough for the stream kernels): the dK/dV kernel stores dS, the dQ kernel is one
-// product over it (fa_bwd_dq_ds.hip) — 5 products instead of 7: -5 ... -7 % of the whole step at 256 x 4096 x 128, -2.6 % under
-// the causal mask there, -2 ... -3 % at config 3 (profiles/r02_ds_handover.md).  Option dq: 6 = always (small launches too),
-// 5 / 8 = never.  The (b,h) units are worked through in equal chunks whose dS fits the chunk size (16 GiB; option ds_chunk_mb),
-// so the workspace is bounded whatever BH is.
+// The dS hand-over (d = 128, no mask, launches big enough for the stream kernels): the dK/dV kernel stores dS, the dQ kernel is
+// one product over it (fa_bwd_dq_ds.hip) — 5 products instead of 7.  The (b,h) units are worked through in equal chunks whose dS
+// fits the chunk size, so the workspace is bounded whatever BH and N are: 4 GiB by default (option ds_chunk_mb).  Whole step at
+// 256 x 4096 x 128 against the recomputing backward (profiles/r03_ds_chunk_sweep.md, one process, interleaved): chunk 8.6 GiB (all
+// units at once) -4.0 %, 4 GiB -3.3 %, 2 GiB -2.3 %, 1 GiB -2.0 %, 512 MiB +3.8 %: every chunk is a launch pair with its own
+// ramp and tail.  Under the causal mask the hand-over is within 1 % of the recomputing stream kernels either way even with the
+// whole launch in one 16 GiB chunk (config 3: 8.60 vs 8.66 ms; N = 4096: 4.91 vs 4.93) and loses from 8 GiB down, for a tile
+// grid half of which is never written: there the recomputing backward — O(N) memory, the property the algorithm is named
+// for (csrc/fa2/fa2_bwd.cu:53-57 keeps O(BH N d) scratch) — is the default and the hand-over is by option only.
+// Option dq: 6 = always (causal and small launches too), 5 / 8 = never.
 static size_t ds_chunk_bytes() {
     const int mb = option(OPT_DS_CHUNK_MB);
-    return mb > 0 ? (size_t)mb << 20 : (size_t)16 << 30;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)4 << 30;
 }
 static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant) {
     const int dq_opt = option(OPT_DQ), dkdv_opt = option(OPT_DKDV);
@@ -365,13 +370,10 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
-    // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead; under the causal mask (half of every (b,h)'s
-    // tile grid stays unwritten and unread, the stores cost the dK/dV kernel 10 %) up to about 768: 16 x 8192 0.75 vs 0.80 ms,
-    // 32 x 4096 0.43 vs 0.46, but 24 x 8192 1.36 vs 1.29, 48 x 4096 0.78 vs 0.77, 256 x 4096 -2.6 % per step (profiles/r02_ds_handover.md).
+    // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
-    if (small_grid(bh, n, true)) return false;
-    if (causal && n <= 1024) return false;   // (there the 8-wave dK/dV kernel is the default: launch_bwd_dkdv_mfma)
-    return !causal || option(OPT_SMALL_GRID) == 1 || bh * ((n + 255) / 256) >= 768;
+    if (causal) return false;
+    return !small_grid(bh, n, true);
 }
 static int64_t ds_chunk_units(int64_t bh, int64_t n) {
     const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));

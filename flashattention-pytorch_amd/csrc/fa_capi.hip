@@ -338,6 +338,13 @@ int fa_ex_forward(const void* q, const void* k, const void* v, void* o, float* l
     if (rc != FA_OK) return rc;
     if (bh == 0 || nq == 0) return FA_OK;
     if (!q || !o || !lse || (nk > 0 && (!k || !v))) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_forward: null tensor pointer");
+    if (nk == 0) {   // no key at all: every row is a row without a visible key, o = 0 and lse = -inf
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        hipError_t e = hipMemsetAsync(o, 0, (size_t)bh * nq * d * (dtype == FA_DTYPE_F32 ? 4 : 2), st);
+        if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lse), (int)0xFF800000u, (size_t)bh * nq, st);
+        if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_ex_forward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+        return FA_OK;
+    }
     fa::ExArgs a{q, k, v, o, lse, nullptr, nullptr, nullptr, nullptr, bh, nq, nk, d, dtype, causal ? 1 : 0, (float)softmax_scale,
                  mask, mask_bh_stride, block_mask, br, bc, dropout_p, dropout_seed, nullptr};
     hipError_t e = fa::launch_ex(a, false, reinterpret_cast<hipStream_t>(stream));
@@ -352,6 +359,21 @@ int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, c
     int rc = ex_check("fa_ex_backward", bh, nq, nk, d, dtype, softmax_scale, block_mask, br, bc, dropout_p);
     if (rc != FA_OK) return rc;
     if (bh == 0 || (nq == 0 && nk == 0)) return FA_OK;
+    if (nq == 0 || nk == 0) {   // one side empty: the gradients of the other side are sums over nothing
+        const size_t es = dtype == FA_DTYPE_F32 ? 4 : 2;
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        hipError_t e = hipSuccess;
+        if (nq == 0) {
+            if (!dk || !dv) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_backward: null tensor pointer");
+            e = hipMemsetAsync(dk, 0, (size_t)bh * nk * d * es, st);
+            if (e == hipSuccess) e = hipMemsetAsync(dv, 0, (size_t)bh * nk * d * es, st);
+        } else {
+            if (!dq) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_backward: null tensor pointer");
+            e = hipMemsetAsync(dq, 0, (size_t)bh * nq * d * es, st);
+        }
+        if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_ex_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+        return FA_OK;
+    }
     if (!q || !k || !v || !o || !do_ || !lse || !dq || !dk || !dv) return fail(FA_ERR_INVALID_ARGUMENT, "fa_ex_backward: null tensor pointer");
     const size_t need = fa_ex_backward_workspace_bytes(bh, nq, nk, d, dtype);
     if (!workspace || workspace_bytes < need)

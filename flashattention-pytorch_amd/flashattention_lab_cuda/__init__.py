@@ -23,6 +23,8 @@ import os
 
 import torch
 
+from .workspace import WorkspaceCache, plan_backward_workspace
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfa_mi355x.so")
 
@@ -154,6 +156,38 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- workspace: one grow-only buffer per (device, stream), see workspace.py ----
+_workspaces = WorkspaceCache(lambda nbytes, device: torch.empty((nbytes,), dtype=torch.uint8, device=device))
+
+
+def _workspace(device, nbytes: int):
+    """The buffer a call on `device`'s current stream works in.  Inside a graph capture it is a plain allocation of the
+    capture's own pool (a cached buffer allocated during capture would outlive the pool it came from)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+    return _workspaces.get(device, _stream_ptr(device), nbytes)
+
+
+def _device_headroom(device) -> int:
+    """Bytes the device could still give this process: driver-free memory + what torch's allocator holds unused."""
+    free, _total = torch.cuda.mem_get_info(device)
+    return int(free) + max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+
+
+def release_workspace(device=None) -> int:
+    """Give the shim's workspace buffers back to torch's allocator (all devices if None).  Returns the bytes released.
+    Call it between phases of a program that no longer runs attention backward; the next call allocates again."""
+    if device is not None:
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device(device.type, torch.cuda.current_device())
+    return _workspaces.release(device)
+
+
+def workspace_stats() -> dict:
+    return {"bytes": _workspaces.total_bytes(), "allocations": _workspaces.allocations, "hits": _workspaces.hits}
+
+
 def _forward(cfn, who, q, k, v, causal, softmax_scale, br, bc, extra=None):
     code = _check_inputs(who, q, k, v)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -167,7 +201,7 @@ def _forward(cfn, who, q, k, v, causal, softmax_scale, br, bc, extra=None):
         if extra is not None:
             stages, fp8 = extra
             nbytes = _lib.fa3_forward_workspace_bytes(bh, n, d, code, int(bool(fp8)))
-            ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=q.device)
+            ws = _workspace(q.device, nbytes)
             args += [int(stages), int(bool(fp8)), ws.data_ptr(), int(nbytes)]
         args.append(_stream_ptr(q.device))
         _check(cfn(*args))
@@ -183,21 +217,19 @@ def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, ext
     lse = lse.contiguous()
     with torch.cuda.device(q.device):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # minimum = row constants (+ FA3's round-tripped Q, K); fast = + room for the dS tiles where the hand-over serves the
+        # call (bounded by the library's chunk size whatever BH is).  The size only selects speed: with the minimum the
+        # library runs its recomputing dQ pass.
+        small = int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
+        fast = int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal))))
         if extra is not None:
-            nbytes = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1]))))
-            # + room for the dS tiles where the backward can use them (the library takes what is left behind its fp8 slabs)
-            nbytes += int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal)))) - int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
-        else:
-            nbytes = int(_lib.fa_backward_workspace_bytes_fast(bh, n, d, code, int(bool(causal))))
-        try:
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
-        except torch.cuda.OutOfMemoryError:
-            # no room for the dS tiles: the minimum workspace makes the library take its recomputing dQ pass
-            small = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1])))) if extra is not None else int(_lib.fa_backward_workspace_bytes(bh, n, d, code))
-            if nbytes == small:
-                raise
-            nbytes = small
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+            fp8_slabs = int(_lib.fa3_backward_workspace_bytes(bh, n, d, code, int(bool(extra[1])))) - small
+            small, fast = small + fp8_slabs, fast + fp8_slabs
+        capturing = torch.cuda.is_current_stream_capturing()
+        have = 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device))
+        nbytes = plan_backward_workspace(small, fast, have, None if have >= fast else _device_headroom(q.device))
+        ws = _workspace(q.device, nbytes)
+        nbytes = max(nbytes, 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device)))
         args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, n, d, code, int(bool(causal)),
                 float(softmax_scale), int(br), int(bc)]
@@ -261,6 +293,7 @@ def _ex_common(who, q, k, v, mask, block_mask, br, bc):
     bptr = 0
     if block_mask is not None:
         block_mask = block_mask.to(device=q.device, dtype=torch.uint8).contiguous()
+        br, bc = max(int(br), 1), max(int(bc), 1)   # (an empty side: Br = min(block_size, 0))
         want = ((nq + br - 1) // br, (nk + bc - 1) // bc)
         if tuple(block_mask.shape) != want:
             raise RuntimeError(f"{who}: block_sparse_mask must be {want} for br={br}, bc={bc}, got {tuple(block_mask.shape)}")
@@ -290,7 +323,7 @@ def ex_backward(q, k, v, o, do_, lse, causal, softmax_scale, mask=None, block_ma
     with torch.cuda.device(q.device):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         nbytes = int(_lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, code))
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        ws = _workspace(q.device, nbytes)
         _check(_lib.fa_ex_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, nq, nk, d, code, int(bool(causal)),
                                    float(softmax_scale), mptr, mstride, bptr, int(br), int(bc), float(dropout_p),

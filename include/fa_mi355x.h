@@ -137,10 +137,12 @@ size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_
  * FA_MODE_BWD_ATOMIC only); ask again after changing the mode */
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype);
 /* The size that lets the backward hand dS from its dK/dV kernel to its dQ kernel instead of recomputing S and dP there
- * (d = 128, 16-bit tensors, launches of > 256 row tiles: N * N * 2 bytes per (b,h), at most 16 GiB — the (b,h) units are
- * worked through in equal chunks; under the causal mask only from 768 row tiles on).  Equals fa_backward_workspace_bytes where that does not apply.  A backward
- * call given less than this (but at least fa_backward_workspace_bytes) runs the recomputing dQ pass: same results up to
- * summation order, 5 - 7 % more time for forward + backward at 256 x 4096 x 128 (2 - 3 % under the causal mask). */
+ * (d = 128, 16-bit tensors, no causal mask, launches of > 256 row tiles: N * N * 2 bytes per (b,h), at most 4 GiB whatever BH
+ * and N are — the (b,h) units are worked through in equal chunks of that size; option ds_chunk_mb moves the bound).  Equals
+ * fa_backward_workspace_bytes where that does not apply: under the causal mask the recomputing backward, which needs O(BH N)
+ * bytes only, is as fast (option dq = 6 forces the hand-over there too).  A backward call given less than this (but at least
+ * fa_backward_workspace_bytes) runs the recomputing dQ pass: same results up to summation order, about 3 % more time for
+ * forward + backward at 256 x 4096 x 128 (profiles/r03_ds_chunk_sweep.md). */
 size_t fa_backward_workspace_bytes_fast(int64_t bh, int64_t n, int64_t d, int dtype, int causal);
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);

@@ -62,3 +62,34 @@ def test_per_algorithm_entry_points_exist_and_refuse_to_run_without_a_gpu():
             r = subprocess.run([sys.executable, path, "--seqlen", "128", "--no-save"], capture_output=True, text=True,
                                cwd=os.path.join(root, "benchmarks"))
             assert r.returncode != 0 and "no CPU backend" in (r.stderr + r.stdout)
+
+
+def test_reference_command_lines_parse_unchanged():
+    """Every flag of the reference's scripts is accepted (bench_compare_all.py:70-91, bench_fa3.py:50-70, bench_fa{1,2}.py:47-50)
+    and --directions defaults to forward as it does there."""
+    import bench_compare_all as bca
+
+    a = bca.build_parser().parse_args([])
+    assert a.directions == ["forward"] and a.tag == "compare_all" and a.no_plot is False and a.config_label is None and a.plot_dtype is None
+    assert a.caption.startswith("Figure 6")
+    a = bca.build_parser("fa3").parse_args(
+        "--device cuda --seqlen 512 16384 --head-dim 64 128 256 --batch-size 1 2 --num-heads 4 --causal --dtypes fp16 bf16 "
+        "--warmup 5 --iters 20 --fp8 --directions forward backward --tag run1 --config-label cfgA --plot-dtype bf16 --no-plot".split()
+        + ["--caption", "Figure 6: x"])
+    assert a.fp8 and a.directions == ["forward", "backward"] and a.tag == "run1" and a.config_label == "cfgA"
+    assert a.plot_dtype == "bf16" and a.no_plot and a.caption == "Figure 6: x" and a.causal and a.seqlen == [512, 16384]
+    assert bca.build_parser("fa2").parse_args(["--non-causal-only", "--no-plot"]).tag == "fa2"
+
+
+def test_cpu_device_is_recorded_not_a_usage_error(tmp_path):
+    """`--device cpu` is a legal reference command line; without a CPU backend every sweep point becomes an error record (with
+    the --config-label in its config field), the table is printed and the exit status is non-zero with the reason."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "benchmarks", "bench_fa3.py"), "--device", "cpu", "--seqlen", "128", "--head-dim", "64",
+                        "--batch-size", "1", "--dtypes", "fp16", "--fp8", "--no-plot", "--config-label", "lbl", "--no-save"],
+                       capture_output=True, text=True, cwd=os.path.join(root, "benchmarks"))
+    assert r.returncode != 0 and "no CPU backend" in r.stderr
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("FA3")]
+    assert len(rows) == 4 and all("error" in ln for ln in rows), r.stdout   # causal x {bf16 path, fp8 path}

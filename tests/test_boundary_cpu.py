@@ -49,14 +49,18 @@ def test_workspace_query_and_argument_validation_without_gpu():
     assert lib.fa_backward_workspace_bytes(4, 128, 64, 2) >= 4 * 128 * 4
     assert lib.fa_backward_workspace_bytes(0, 0, 64, 2) > 0
     # the dS hand-over's size: N * N * 2 bytes per (b,h) on top of the minimum where it serves the call (d = 128, 16-bit, no
-    # launch of > 256 row tiles), at most 16 GiB (equal chunks of (b,h) units); the minimum everywhere else
+    # mask, launches of > 256 row tiles), at most 4 GiB (equal chunks of (b,h) units); the minimum everywhere else
     base = lib.fa_backward_workspace_bytes(256, 4096, 128, 2)
-    assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 0) == base + 256 * 4096 * 4096 * 2
-    assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 1) == base + 256 * 4096 * 4096 * 2   # the same under the mask
-    assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 1) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2)   # ... from 768 tiles on
+    assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 0) == base + 128 * 4096 * 4096 * 2   # two chunks of 128 units
+    assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 1) == base    # causal: the recomputing backward, O(BH N) bytes
+    assert lib.fa_backward_workspace_bytes_fast(128, 8192, 128, 2, 1) == lib.fa_backward_workspace_bytes(128, 8192, 128, 2)
     assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 0) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2) + 32 * 4096 * 4096 * 2
-    assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 512 * 4096 * 4096 * 2
-    assert lib.fa_backward_workspace_bytes_fast(600, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(600, 4096, 128, 1) + 300 * 4096 * 4096 * 2   # 2 x 300, not 512 + 88
+    assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 128 * 4096 * 4096 * 2
+    assert lib.fa_backward_workspace_bytes_fast(300, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(300, 4096, 128, 1) + 100 * 4096 * 4096 * 2   # 3 x 100, not 128 + 128 + 44
+    assert lib.fa_backward_workspace_bytes_fast(64, 32768, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 32768, 128, 2) + 2 * 32768 * 32768 * 2   # 2 units of 2 GiB per chunk
+    assert lib.fa_backward_workspace_bytes_fast(64, 65536, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 65536, 128, 2)   # one unit alone is over the bound
+    for bh_, n_ in ((1, 4096), (256, 4096), (4096, 4096), (100, 16384), (7, 40000), (3, 100000)):    # bounded whatever BH and N are
+        assert lib.fa_backward_workspace_bytes_fast(bh_, n_, 128, 2, 0) - lib.fa_backward_workspace_bytes(bh_, n_, 128, 2) <= 4 << 30
     assert lib.fa_backward_workspace_bytes_fast(80, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(80, 1000, 128, 2) + 80 * 32 * 32 * 2048  # ragged N: whole tiles
     assert lib.fa_backward_workspace_bytes_fast(64, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 1000, 128, 2)  # 256 tiles of 256 rows: still the recomputing pass
     assert lib.fa_backward_workspace_bytes_fast(2, 512, 128, 2, 0) == lib.fa_backward_workspace_bytes(2, 512, 128, 2)     # small launch

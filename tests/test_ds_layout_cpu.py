@@ -97,7 +97,7 @@ def test_workspace_sizes_are_the_tile_grid():
     for bh, n in ((256, 4096), (80, 1000), (128, 8192), (300, 4100)):
         tiles = ((n + 31) // 32) * (8 * ((n + 255) // 256))          # 32-query blocks x 32-key blocks (keys padded to 256-key tiles)
         per_unit = tiles * 2048
-        fit = (16 << 30) // per_unit
+        fit = (4 << 30) // per_unit
         parts = -(-bh // fit)
         units = bh if fit >= bh else -(-bh // parts)                 # equal chunks
         extra = lib.fa_backward_workspace_bytes_fast(bh, n, 128, 2, 0) - lib.fa_backward_workspace_bytes(bh, n, 128, 2)

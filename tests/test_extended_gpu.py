@@ -262,3 +262,30 @@ def test_autograd_wrapper_and_error_behaviour(device):
                        mask=torch.ones(20, 49, dtype=torch.uint8, device=device))
     with pytest.raises(RuntimeError, match="dropout_p"):
         ext.ex_forward(q.detach().reshape(6, 20, 32), k.detach().reshape(6, 50, 32), v.detach().reshape(6, 50, 32), False, 0.1, dropout_p=1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_an_empty_side_gives_zero_gradients_and_minus_infinity_lse(dtype, device):
+    """nq == 0 with nk > 0 (dK = dV = 0) and nk == 0 with nq > 0 (o = 0, lse = -inf, dQ = 0) — sums over nothing,
+    not a launch with an empty grid; a block-sparse mask with an empty side does not divide by Br = 0 either."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 3, 40, 32
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn((bh, n, d), generator=g).to(dtype).to(device)
+    empty = torch.empty((bh, 0, d), dtype=dtype, device=device)
+    # no queries
+    o, lse = ext.ex_forward(empty, full, full, False, 0.2)
+    assert o.shape == (bh, 0, d) and lse.shape == (bh, 0)
+    dq, dk, dv = ext.ex_backward(empty, full, full, o, empty, lse, False, 0.2)
+    assert dq.shape == (bh, 0, d) and not dk.any() and not dv.any()
+    dq, dk, dv = ext.ex_backward(empty, full, full, o, empty, lse, True, 0.2, block_mask=torch.ones((0, 2), dtype=torch.uint8, device=device),
+                                 br=0, bc=32, dropout_p=0.1, seed=3)
+    assert not dk.any() and not dv.any()
+    # no keys
+    o, lse = ext.ex_forward(full, empty, empty, True, 0.2)
+    assert not o.any() and torch.isinf(lse).all() and (lse < 0).all()
+    dq, dk, dv = ext.ex_backward(full, empty, empty, o, full, lse, True, 0.2)
+    assert not dq.any() and dk.shape == (bh, 0, d) and dv.shape == (bh, 0, d)
+    torch.cuda.synchronize()

@@ -83,3 +83,31 @@ def test_host_module_argument_handling_without_gpu():
     assert torch.equal(m[0, 0], orc.extended_visible(1, 3, 5, causal=True)[0])
     with pytest.raises(RuntimeError, match="CUDA tensors"):
         flash_attention_ex(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4))
+
+
+def test_mask_normalisation_follows_ordinary_broadcasting():
+    """`mask` is "broadcastable to (B, H, Nq, Nk)" (flashattention_pytorch.py:139-141 indexes it as 4-D and lets
+    masked_fill broadcast): key-padding masks with a singleton query dim, per-batch masks with a singleton head dim, shared masks."""
+    from common.attention_ex import normalize_mask
+
+    b, h, nq, nk = 2, 3, 5, 7
+    g = torch.Generator().manual_seed(0)
+    full = torch.rand((b, h, nq, nk), generator=g) > 0.4
+    want = lambda m: torch.broadcast_to(m, (b, h, nq, nk)).reshape(b * h, nq, nk)   # noqa: E731
+    # shared forms -> (Nq, Nk)
+    for m in (full[0, 0], full[:1, :1], full[:1, :1, :1, :], full[0, 0, :1]):
+        got = normalize_mask(m, (b, h), nq, nk)
+        assert got.shape == (nq, nk) and torch.equal(got, torch.broadcast_to(m, (1, 1, nq, nk))[0, 0])
+    # per-(b,h) forms -> (BH, Nq, Nk)
+    for m in (full, full[:, :1], full[:1], full[:, :1, :1, :], full[:, :, :, :1], full[0]):   # the last: (H, Nq, Nk), aligned from the right
+        got = normalize_mask(m, (b, h), nq, nk)
+        assert got.shape == (b * h, nq, nk) and torch.equal(got, want(m)), m.shape
+    # merged (BH, N, d) tensors: (BH, Nq, Nk), (1, Nq, Nk), (Nq, Nk), and a 4-D mask whose leading dims multiply to BH
+    assert torch.equal(normalize_mask(full.reshape(b * h, nq, nk), (b * h,), nq, nk), full.reshape(b * h, nq, nk))
+    assert normalize_mask(full[0, :1], (b * h,), nq, nk).shape == (nq, nk)
+    assert torch.equal(normalize_mask(full, (b * h,), nq, nk), full.reshape(b * h, nq, nk))
+    assert normalize_mask((full[0, 0]).to(torch.uint8), (b * h,), nq, nk).dtype == torch.bool   # 0 / 1 tensors too
+    with pytest.raises(RuntimeError, match="does not broadcast"):
+        normalize_mask(full[:, :2], (b, h), nq, nk)
+    with pytest.raises(RuntimeError, match="does not broadcast"):
+        normalize_mask(full, (5,), nq, nk)

@@ -276,13 +276,14 @@ def test_benchmark_harness_runs_on_the_gpu():
     import bench_utils as bu
 
     recs = bench_compare_all.main(["--seqlen", "512", "--head-dim", "64", "--batch-size", "1", "--num-heads", "4", "--iters", "2",
-                                   "--warmup", "1", "--no-save", "--fp8"])
+                                   "--warmup", "1", "--no-save", "--fp8", "--directions", "forward", "backward", "--no-plot",
+                                   "--config-label", "gpu-suite"])
     # directions(2) x causal(2) x dtypes(2) x (fa1, fa2, fa3, fa3+fp8)
     assert len(recs) == 2 * 2 * 2 * 4
     for r in recs:
         assert list(r.to_dict().keys()) == bu.FIELDS
         assert r.status == "ok", (r.method, r.direction, r.dtype, r.error)
-        assert r.mean_ms > 0 and r.tflops > 0 and r.backend == "cuda"
+        assert r.mean_ms > 0 and r.tflops > 0 and r.backend == "cuda" and r.config == "gpu-suite"
 
 
 def test_error_behaviour_matches_reference(device):
@@ -726,11 +727,10 @@ def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device)
     ext.set_option("dq", 6)
     ext.set_option("ds_chunk_mb", per_unit_mb)
     ext.set_option("dq_w4", 3 if rows == 256 else 0)   # the dQ product kernel's 4-wave / 256-row form (default: 8 waves, 512 rows)
-    # the workspace the shim is about to get from torch's caching allocator: full of NaN patterns (a dS tile the dK/dV kernel
-    # did not write — blocks the causal mask removes, tiles past a ragged end — must not be read)
-    junk = torch.full((int(ext._lib.fa_backward_workspace_bytes_fast(bh, n, d, 2 if dtype == torch.bfloat16 else 1, int(causal))),), 0xFF,
-                      dtype=torch.uint8, device=device)
-    del junk
+    # the shim's workspace buffer for this stream, grown to what the call will ask for and filled with NaN patterns (a dS tile the
+    # dK/dV kernel did not write — blocks the causal mask removes, tiles past a ragged end — must not be read)
+    nbytes = int(ext._lib.fa_backward_workspace_bytes_fast(bh, n, d, 2 if dtype == torch.bfloat16 else 1, int(causal)))
+    ext._workspace(torch.device(device, torch.cuda.current_device()), nbytes).fill_(0xFF)
     try:
         o, lse, dq, dk, dv = _run(2, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device))
     finally:
@@ -789,3 +789,78 @@ def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_re
     assert rc == 0 and "bwd_delta" not in prof2
     for a, b in zip((dq2, dk2, dv2), ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_memory_is_bounded_at_the_config4_shard(causal, device):
+    """the backward's device memory at 256 x 4096 x 128 (config 4's per-GPU shard) is its three outputs + a
+    workspace that does not grow with BH or N: 4 GiB of dS tiles (two chunks of 128 units) + 8 MiB of row constants without the
+    mask, the 8 MiB alone under it (recomputing backward).  The workspace is the shim's persistent buffer: a second call
+    allocates nothing but its outputs.  The reference keeps O(BH N d) scratch (csrc/fa2/fa2_bwd.cu:53-57)."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 256, 4096, 128
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=23, device=device)
+    o, lse = ext.forward(q, k, v, causal, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    ext.release_workspace()
+    tensor = bh * n * d * 2
+    bound = 3 * tensor + (0 if causal else 4 << 30) + (8 << 20) + (2 << 20)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    ext.profile_enable(True)
+    dq, dk, dv = ext.backward(q, k, v, o, do, lse, causal, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    prof = ext.profile_report()
+    ext.profile_enable(False)
+    first = torch.cuda.max_memory_allocated() - base
+    assert first <= bound, (first, bound)
+    assert ext.workspace_stats()["bytes"] <= (0 if causal else 4 << 30) + (9 << 20)
+    if not causal:   # the hand-over ran, in two chunks: one preparation launch, two dK/dV + dQ launch pairs
+        assert prof["bwd_delta"][0] == 1 and prof["bwd_mfma"][0] == 2 and prof["bwd_dq_mfma"][0] == 2, prof
+    else:
+        assert "bwd_delta" not in prof, prof
+    allocs = ext.workspace_stats()["allocations"]
+    del dq, dk, dv
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    dq, dk, dv = ext.backward(q, k, v, o, do, lse, causal, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base <= 3 * tensor + (1 << 20)      # outputs only
+    assert ext.workspace_stats()["allocations"] == allocs                          # the buffer was reused
+    # same gradients as the recomputing pass (summation order differs)
+    ext.set_option("dq", 5)
+    try:
+        ref = ext.backward(q, k, v, o, do, lse, causal, d ** -0.5, 64, 128)
+    finally:
+        ext.set_option("dq", 0)
+    for a, b in zip((dq, dk, dv), ref):
+        assert max_abs(a, b) <= 2e-2 * b.float().abs().max().item()
+    ext.release_workspace()
+
+
+def test_workspace_falls_back_to_the_minimum_when_the_device_is_full(device, monkeypatch):
+    """No allocate-fail-retry: with too little headroom the shim asks for the minimum workspace up front and the
+    library runs its recomputing dQ pass; nothing raises, nothing synchronises."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 64, 4096, 128
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=29, device=device)
+    o, lse = ext.forward(q, k, v, False, d ** -0.5, 64, 128)
+    ext.release_workspace()
+    monkeypatch.setattr(ext, "_device_headroom", lambda dev: 1 << 30)   # as if 1 GiB were left; the hand-over wants 2 GiB
+    ext.profile_enable(True)
+    got = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    torch.cuda.synchronize()
+    prof = ext.profile_report()
+    ext.profile_enable(False)
+    assert "bwd_delta" not in prof and ext.workspace_stats()["bytes"] <= 16 << 20, (prof, ext.workspace_stats())
+    monkeypatch.undo()
+    ext.set_option("dq", 5)
+    try:
+        ref = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    finally:
+        ext.set_option("dq", 0)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    ext.release_workspace()

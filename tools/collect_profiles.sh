@@ -27,7 +27,7 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq" -- python3 "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 > "$OUT/pmc_sq.log" 2>&1)
 echo "== fp8 + harness"; date
 python3 tools/bench_fp8.py > "$OUT/fp8_forward_config5.json" 2> "$OUT/fp8.err"
-(cd benchmarks && python3 bench_compare_all.py --seqlen 512 2048 8192 --head-dim 64 128 --batch-size 2 --num-heads 4 --dtypes bf16 --iters 10 --warmup 3 --fp8 --tag "$R" > "$OUT/harness_table.txt" 2> "$OUT/harness.err")
+(cd benchmarks && python3 bench_compare_all.py --seqlen 512 2048 8192 --head-dim 64 128 --batch-size 2 --num-heads 4 --dtypes bf16 --iters 10 --warmup 3 --fp8 --directions forward backward --no-plot --tag "$R" > "$OUT/harness_table.txt" 2> "$OUT/harness.err")
 cp benchmarks/results/*"$R"*.json "$OUT/" 2>/dev/null
 python3 tools/w4_cycles.py --kernel dkdv > "$OUT/cycles_dkdv.md" 2>/dev/null
 python3 tools/w4_cycles.py --kernel dq > "$OUT/cycles_dq.md" 2>/dev/null
