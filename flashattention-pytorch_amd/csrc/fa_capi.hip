@@ -40,8 +40,8 @@ hipEvent_t prof_get_event() {
 }
 
 // ---- tuning knobs ---------------------------------------------------------------------------------
-constexpr const char* kOptNames[fa::OPT_COUNT] = {"fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "dkdv_abl", "dq", "dq_abl", "ex_path", "ds_chunk_mb"};
-constexpr const char* kOptEnv[fa::OPT_COUNT] = {"FA_FWD_KB", "FA_FWD_STAG", "FA_DKDV", "FA_DQ_KT", "FA_FWD_RS", "FA_DKDV_KREG", "FA_FWD_EAGER", "FA_FWD_HS", "FA_FWD_TPW", "FA_DQ_TPW", "FA_DKDV_TPW", "FA_DQ_NLF", "FA_DQ_W4", "FA_FWD_ABL", "FA_SMALL_GRID", "FA_FP8_ROT", "FA_DKDV_STG", "FA_DKDV_ABL", "FA_DQ", "FA_DQ_ABL", "FA_EX_PATH", "FA_DS_CHUNK_MB"};
+constexpr const char* kOptNames[fa::OPT_COUNT] = {"fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "dkdv_abl", "dq", "dq_abl", "ex_path", "ds_chunk_mb", "fp8_pv"};
+constexpr const char* kOptEnv[fa::OPT_COUNT] = {"FA_FWD_KB", "FA_FWD_STAG", "FA_DKDV", "FA_DQ_KT", "FA_FWD_RS", "FA_DKDV_KREG", "FA_FWD_EAGER", "FA_FWD_HS", "FA_FWD_TPW", "FA_DQ_TPW", "FA_DKDV_TPW", "FA_DQ_NLF", "FA_DQ_W4", "FA_FWD_ABL", "FA_SMALL_GRID", "FA_FP8_ROT", "FA_DKDV_STG", "FA_DKDV_ABL", "FA_DQ", "FA_DQ_ABL", "FA_EX_PATH", "FA_DS_CHUNK_MB", "FA_FP8_PV"};
 // a name added to OptionId without its two strings here would leave a null at the end of a table
 template <size_t N> constexpr bool all_set(const char* const (&t)[N]) {
     for (size_t i = 0; i < N; ++i)
@@ -108,13 +108,16 @@ bool use_mfma_bwd(int dtype, int64_t n, int64_t d, double s, std::initializer_li
            fa::bwd_mfma_supported(dtype, d);
 }
 
-// Does an fa3 call with fp8 = 1 take the e4m3 Q/K path?  ONE predicate for fa3_forward and fa3_backward, over arguments
-// that are the same in both calls (the workspace is not: a misaligned one is an error there), so that the backward
-// always differentiates the function the forward evaluated.
+// Does an fa3 call with fp8 = 1 take the e4m3 path?  ONE predicate for fa3_forward and fa3_backward, over arguments that are the
+// same in both calls (the workspace is not: a misaligned one is an error there), so that the backward always differentiates the
+// function the forward evaluated.  It holds wherever the 16-bit MFMA kernels serve the call (f16 / bf16 tensors, head dims that
+// are multiples of 8 up to 256): Q, K and V then go through OCP e4m3 with one scale per 64-row block, as the reference's wiring
+// has it (csrc/fa3/fa3_fwd.cu:196-208) — at d = 128 on the e4m3 MFMA kernel, elsewhere as a round trip ahead of the 16-bit kernels.
 bool fp8_path(int dtype, int64_t n, int64_t d, double s, const void* q, const void* k, const void* v, const void* o) {
-    return fa::fwd_fp8_supported(dtype, d) && scale_ok(s) && g_mode.load() != FA_MODE_F32_GENERIC && slab_ok(n, d) &&
-           aligned16({q, k, v, o});
+    return fa::fwd_mfma_supported(dtype, d) && fa::bwd_mfma_supported(dtype, d) && scale_ok(s) && g_mode.load() != FA_MODE_F32_GENERIC &&
+           slab_ok(n, d) && aligned16({q, k, v, o});
 }
+size_t slab_bytes(int64_t bh, int64_t n, int64_t d) { return ((size_t)bh * n * d * 2 + 255) & ~(size_t)255; }   // one round-tripped 16-bit tensor
 
 int forward_impl(const char* who, const void* q, const void* k, const void* v, void* o, float* lse, int64_t bh,
                  int64_t n, int64_t d, int dtype, int causal, double scale, void* stream) {
@@ -263,9 +266,8 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
                 int dtype, int causal, double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8,
                 void* workspace, size_t workspace_bytes, void* stream) {
     (void)br; (void)bc; (void)stages;
-    // fp8 is a permission to use the e4m3 Q/K path, honoured where that kernel exists (16-bit tensors, d = 128,
-    // positive scale); every other shape takes the regular, more accurate path (as the reference quietly skips its
-    // rotation for non-power-of-two d, src/fa3/torch/impl.py:60-61).
+    // fp8: Q, K and V through e4m3 (see fp8_path).  fp32 tensors and head dims the 16-bit kernels do not take run the regular,
+    // more accurate path (as the reference quietly skips its rotation for non-power-of-two d, src/fa3/torch/impl.py:60-61).
     if (fp8 && fp8_path(dtype, n, d, softmax_scale, q, k, v, o)) {
         int rc = check_common("fa3_forward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
@@ -274,8 +276,25 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
         const size_t need = fa3_forward_workspace_bytes(bh, n, d, dtype, 1);
         if (!workspace || workspace_bytes < need || !aligned16({workspace}))
             return fail(FA_ERR_WORKSPACE, "fa3_forward: a 16-byte aligned workspace of %zu bytes is needed, %zu given", need, workspace_bytes);
-        fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
-        hipError_t e = fa::launch_fwd_fp8(a, workspace, reinterpret_cast<hipStream_t>(stream));
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const size_t slab = slab_bytes(bh, n, d);
+        char* ws = reinterpret_cast<char*>(workspace);
+        hipError_t e;
+        if (fa::fwd_fp8_supported(dtype, d)) {
+            // d = 128: [V~][the e4m3 kernels' own workspace: Q, K, V^T bytes and scales].  Default: S and P.V on the e4m3 MFMA;
+            // option fp8_pv = 1: S on the e4m3 MFMA, P.V 16-bit on the round-tripped V.
+            const bool pv16 = fa::option(fa::OPT_FP8_PV) == 1;
+            e = pv16 ? fa::launch_fp8_roundtrip(nullptr, nullptr, v, nullptr, nullptr, ws, bh, n, d, dtype, st) : hipSuccess;
+            if (e == hipSuccess) {
+                fa::FwdArgs a{q, k, pv16 ? (const void*)ws : v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
+                e = fa::launch_fwd_fp8(a, ws + slab, st);
+            }
+        } else {
+            // [Q~][K~][V~] (original basis), then the 16-bit kernels as they are
+            e = fa::launch_fp8_roundtrip(q, k, v, ws, ws + slab, ws + 2 * slab, bh, n, d, dtype, st);
+            if (e == hipSuccess)
+                return forward_impl("fa3_forward", ws, ws + slab, ws + 2 * slab, o, lse, bh, n, d, dtype, causal, softmax_scale, stream);
+        }
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_forward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
         return FA_OK;
     }
@@ -287,27 +306,25 @@ int fa3_backward(const void* q, const void* k, const void* v, const void* o, con
                  double softmax_scale, int64_t br, int64_t bc, int64_t stages, int fp8, void* workspace,
                  size_t workspace_bytes, void* stream) {
     (void)br; (void)bc; (void)stages;
-    // fp8: differentiate the function the forward evaluated, i.e. attention of the e4m3-round-tripped Q and K
+    // fp8: differentiate the function the forward evaluated, i.e. attention of the e4m3-round-tripped Q, K and V
     // (the reference's fa3_backward does the same, csrc/fa3/fa3_bwd.cu:134-146); the gradients are returned for
-    // q, k themselves (straight-through over the rounding).  o and lse then match the recomputed probabilities.
+    // q, k, v themselves (straight-through over the rounding).  o and lse then match the recomputed probabilities.
     if (fp8 && fp8_path(dtype, n, d, softmax_scale, q, k, v, o) && bh > 0 && n > 0) {
         int rc = check_common("fa3_backward", bh, n, d, dtype, softmax_scale);
         if (rc != FA_OK) return rc;
-        if (!q || !k) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_backward: null tensor pointer");
-        const size_t base_need = fa_backward_workspace_bytes(bh, n, d, dtype);
+        if (!q || !k || !v) return fail(FA_ERR_INVALID_ARGUMENT, "fa3_backward: null tensor pointer");
         const size_t need = fa3_backward_workspace_bytes(bh, n, d, dtype, 1);
         if (!workspace || workspace_bytes < need || !aligned16({workspace}))
             return fail(FA_ERR_WORKSPACE, "fa3_backward: a 16-byte aligned workspace of %zu bytes is needed, %zu given", need, workspace_bytes);
-        // layout: [round-tripped Q][round-tripped K][pad to 256][the plain backward's workspace: everything that is left, so a
-        // caller who sized it with fa_backward_workspace_bytes_fast's surplus gets the dS hand-over here too]
-        (void)base_need;
-        const size_t slabs = (2 * (size_t)bh * n * d * 2 + 255) & ~(size_t)255;
+        // layout: [Q~][K~][V~][the plain backward's workspace: everything that is left, so a caller who sized it with
+        // fa_backward_workspace_bytes_fast's surplus gets the dS hand-over here too]
+        const size_t slab = slab_bytes(bh, n, d);
         char* qt = reinterpret_cast<char*>(workspace);
-        char* kt = qt + (size_t)bh * n * d * 2;
-        hipError_t e = fa::launch_fp8_roundtrip(q, k, qt, kt, bh, n, dtype, reinterpret_cast<hipStream_t>(stream));
+        char *kt = qt + slab, *vt = qt + 2 * slab;
+        hipError_t e = fa::launch_fp8_roundtrip(q, k, v, qt, kt, vt, bh, n, d, dtype, reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa3_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
-        return backward_impl("fa3_backward", qt, kt, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
-                             qt + slabs, workspace_bytes - slabs, stream);
+        return backward_impl("fa3_backward", qt, kt, vt, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
+                             qt + 3 * slab, workspace_bytes - 3 * slab, stream);
     }
     return backward_impl("fa3_backward", q, k, v, o, do_, lse, dq, dk, dv, bh, n, d, dtype, causal, softmax_scale,
                          workspace, workspace_bytes, stream);
@@ -393,7 +410,7 @@ size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_
 
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
     size_t need = fa_backward_workspace_bytes(bh, n, d, dtype);
-    if (fp8 && bh > 0 && n > 0 && d > 0 && fa::fwd_fp8_supported(dtype, d)) need += 2 * (size_t)bh * n * d * 2 + 256;
+    if (fp8 && bh > 0 && n > 0 && d > 0 && fa::fwd_mfma_supported(dtype, d) && fa::bwd_mfma_supported(dtype, d)) need += 3 * slab_bytes(bh, n, d);
     return need;
 }
 
@@ -413,8 +430,9 @@ size_t fa_backward_workspace_bytes_fast(int64_t bh, int64_t n, int64_t d, int dt
 }
 
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {
-    if (!fp8 || bh <= 0 || n <= 0 || d <= 0 || !fa::fwd_fp8_supported(dtype, d)) return 0;
-    return fa::fwd_fp8_workspace_bytes(bh, n, d);
+    if (!fp8 || bh <= 0 || n <= 0 || d <= 0 || !fa::fwd_mfma_supported(dtype, d) || !fa::bwd_mfma_supported(dtype, d)) return 0;
+    if (fa::fwd_fp8_supported(dtype, d)) return slab_bytes(bh, n, d) + fa::fwd_fp8_workspace_bytes(bh, n, d);
+    return 3 * slab_bytes(bh, n, d);
 }
 
 int fa_debug_trace_buffer(void* device_ptr) {

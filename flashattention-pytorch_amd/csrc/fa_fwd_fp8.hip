@@ -123,6 +123,102 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const uint16_t* __restri
     }
 }
 
+// The e4m3 round trip of whole tensors, any head dim that is a multiple of 8 (up to 256): x -> dequantise(quantise(x)) with one
+// absmax scale per (b,h, 64-row block), written back as 16-bit tensors.  This is the reference's own wiring of its fp8 mode —
+// quantise-dequantise Q, K AND V ahead of the unchanged inner loops (csrc/fa3/fa3_fwd.cu:196-208, fa3_bwd.cu:134-146,
+// src/fa3/torch/impl.py:123-131) — with a real 8-bit rounding in place of its fp16 no-op.  ROT (Q and K, power-of-two
+// head dims: src/fa3/torch/impl.py:60-61 skips the others too): rotate, quantise, and rotate back, so that the round-tripped
+// tensors live in the original basis and any kernel can consume them: (Q~ R^T)(K~ R^T)^T = Q~ K~^T.
+// Serves: fa3_forward(fp8) for head dims without an e4m3 MFMA kernel (then the 16-bit kernels run on Q~, K~, V~), the V of the
+// d = 128 kernel's bf16 P.V variant, and fa3_backward(fp8) at every head dim (it differentiates the function the forward evaluated).
+struct Fp8RtArgs {
+    const uint16_t* src[3];
+    uint16_t* dst[3];
+    int rot[3];
+};
+template <typename Tag>
+__global__ __launch_bounds__(256) void fp8_roundtrip_kernel(Fp8RtArgs a, int n, int d) {
+    constexpr int MAXI = 8;                     // 64 rows x 32 chunks (d = 256) over 256 threads
+    __shared__ float red[4];
+    const int z = blockIdx.z, bh = blockIdx.y, row0 = blockIdx.x * 64;
+    const uint16_t* src = a.src[z];
+    uint16_t* dst = a.dst[z];
+    const bool rot = a.rot[z] != 0;             // the host sets it only for power-of-two d: a row is then cpr <= 32 consecutive lanes
+    const int cpr = d >> 3, total = 64 * cpr;   // 16-byte chunks per row / per block
+    const size_t base = (size_t)bh * n * d;
+    const float rs = rsqrtf((float)d);
+    float xf[MAXI][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = threadIdx.x + 256 * i, row = row0 + c / cpr, ch = c % cpr;
+        u32x4 x = u32x4{0u, 0u, 0u, 0u};
+        if (c < total && row < n) x = *reinterpret_cast<const u32x4*>(src + base + (size_t)row * d + 8 * ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xf[i][2 * j] = unpack_lo<Tag>(x[j]); xf[i][2 * j + 1] = unpack_hi<Tag>(x[j]); }
+        if (rot) {   // block-uniform branch; every lane of the wave takes part in the shuffles
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[i][j] *= rot_sign(8 * ch + j);
+#pragma unroll
+            for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (!(j & st)) { const float p = xf[i][j], m = xf[i][j | st]; xf[i][j] = p + m; xf[i][j | st] = p - m; }
+            for (int bit = 1; bit < cpr; bit <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float other = __shfl_xor(xf[i][j], bit, 64);
+                    xf[i][j] = (ch & bit) ? other - xf[i][j] : xf[i][j] + other;
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[i][j] *= rs;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(xf[i][j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-6f);   // eps of block_absmax_scale
+    const float inv = kE4M3Max / amax, scl = amax / kE4M3Max;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = threadIdx.x + 256 * i, row = row0 + c / cpr, ch = c % cpr;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][0] * inv, xf[i][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][2] * inv, xf[i][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][4] * inv, xf[i][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][6] * inv, xf[i][7] * inv, w1, true);
+        const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+        const f32x2_t a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+        float y[8] = {a0[0] * scl, a0[1] * scl, a1[0] * scl, a1[1] * scl, a2[0] * scl, a2[1] * scl, a3[0] * scl, a3[1] * scl};
+        if (rot) {   // back to the original basis: H, then the signs (the rotation's transpose)
+#pragma unroll
+            for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (!(j & st)) { const float p = y[j], m = y[j | st]; y[j] = p + m; y[j | st] = p - m; }
+            for (int bit = 1; bit < cpr; bit <<= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float other = __shfl_xor(y[j], bit, 64);
+                    y[j] = (ch & bit) ? other - y[j] : y[j] + other;
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] *= rs * rot_sign(8 * ch + j);
+        }
+        if (c >= total || row >= n) continue;
+        u32x4 o4;
+        o4[0] = pack2_rn<Tag>(y[0], y[1]);
+        o4[1] = pack2_rn<Tag>(y[2], y[3]);
+        o4[2] = pack2_rn<Tag>(y[4], y[5]);
+        o4[3] = pack2_rn<Tag>(y[6], y[7]);
+        *reinterpret_cast<u32x4*>(dst + base + (size_t)row * d + 8 * ch) = o4;
+    }
+}
+
 template <typename Tag, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
                                                          const float* __restrict__ sq, const float* __restrict__ sk,
@@ -284,63 +380,324 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
     }
 }
 
-bool fwd_fp8_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
-
-// workspace: [q8: BH*N*D bytes][k8: BH*N*D bytes][sq: BH*nb floats][sk: BH*nb floats], nb = ceil(N/64)
-size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d) {
-    const size_t nb = (size_t)((n + 63) / 64);
-    size_t bytes = 2 * (size_t)bh * n * d;
-    bytes = (bytes + 255) & ~(size_t)255;
-    return bytes + 2 * sizeof(float) * (size_t)bh * nb + 256;
+// ---- the all-e4m3 forward (default at d = 128; option fp8_pv = 1 selects the kernel above with its 16-bit P.V) -------------
+// V goes through e4m3 as well and P.V runs on the block-scaled fp8 MFMA too: per 128-key tile and wave 8 + 8 MFMAs of 64 cycles
+// where the 16-bit kernel issues 32 + 32 of 32 cycles — half the matrix time, which leaves the kernel bound by the softmax's
+// vector work.  What that needs:
+//   * V^T as the A operand of O^T += V^T P^T, 32 contiguous bytes (= 32 keys) per lane: fp8_quant_v_kernel writes V TRANSPOSED,
+//     tile by tile — [b,h][128-key tile][d row 0..127][128 key bytes], one tile = 16 KiB contiguous = byte for byte the geometry of
+//     the K tile — with the keys of every 64-key group permuted into the order in which the S^T accumulators hold them:
+//     byte 32 hi + 16 h + jj of a group is key 32 hi + 4 h + (jj & 3) + 8 (jj >> 2).  The e4m3 P of two 32-key blocks (registers
+//     0..15 of block 2g, then of block 2g+1) is then the B operand as it stands, and lane (d row, h) reads chunks 4g + h and
+//     4g + 2 + h of its row exactly as the S product reads its K rows.
+//   * one V scale per 64-key block that the MFMA can apply itself: a power of two (2^e >= absmax / 448), handed to the
+//     instruction as the E8M0 block scale of its A operand.  Keys past N are written as zeros (their P is 0: 0 x 0).
+//   * P in e4m3: p = exp2(s - m) lies in (0, 256] under the lazy rescale, inside e4m3's range (448); the row sum and lse come
+//     from the f32 p, so only O sees the 3-bit mantissa (about 1e-2 absolute at N = 16384, inside the reference's 1e-1 bar).
+template <typename Tag>
+__global__ __launch_bounds__(256) void fp8_quant_v_kernel(const uint16_t* __restrict__ v, uint8_t* __restrict__ v8t,
+                                                          int* __restrict__ svexp, int n, int nb, int ntile) {
+    constexpr int D = 128, CPR = D / 8, PER = (64 * CPR) / 256;
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) uint8_t tr[D * 64];   // [d row][permuted key position]
+    const int bh = blockIdx.y, blk = blockIdx.x, row0 = blk * 64;
+    const size_t base = (size_t)bh * n * D;
+    float xf[PER][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i, row = row0 + c / CPR, ch = c % CPR;
+        u32x4 x = u32x4{0u, 0u, 0u, 0u};
+        if (row < n) x = *reinterpret_cast<const u32x4*>(v + base + (size_t)row * D + 8 * ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xf[i][2 * j] = unpack_lo<Tag>(x[j]); xf[i][2 * j + 1] = unpack_hi<Tag>(x[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(xf[i][j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-6f);
+    // smallest power of two 2^e with amax / 2^e <= 448 (exponent arithmetic on the f32 bits: exact)
+    int e = (int)((__float_as_uint(amax / kE4M3Max) >> 23) & 0xff) - 127;
+    if (__uint_as_float((unsigned)(e + 127) << 23) * kE4M3Max < amax) ++e;
+    e = max(-126, min(126, e));
+    const float inv = __uint_as_float((unsigned)(127 - e) << 23);   // 2^-e
+    if (threadIdx.x == 0) svexp[(size_t)bh * nb + blk] = e + 127;   // E8M0
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i, key = c / CPR, ch = c % CPR;   // key within the 64-key block
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][0] * inv, xf[i][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][2] * inv, xf[i][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][4] * inv, xf[i][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(xf[i][6] * inv, xf[i][7] * inv, w1, true);
+        const int wlo = key & 31, pos = 32 * (key >> 5) + 16 * ((wlo >> 2) & 1) + (wlo & 3) + 4 * (wlo >> 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr[(8 * ch + j) * 64 + pos] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xff);
+    }
+    __syncthreads();
+    // d row r of the block: 64 bytes at [tile blk / 2][r][64 (blk & 1) ...]; a thread stores half a row
+    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+    uint8_t* dst = v8t + (((size_t)bh * ntile + (blk >> 1)) * D + r) * 128 + 64 * (blk & 1) + 32 * half;
+    const u32x4* src = reinterpret_cast<const u32x4*>(tr + r * 64 + 32 * half);
+    reinterpret_cast<u32x4*>(dst)[0] = src[0];
+    reinterpret_cast<u32x4*>(dst)[1] = src[1];
+    // an odd block count leaves the second half of the last tile unwritten by any block: zero it (those keys lie past N)
+    if ((nb & 1) && blk == nb - 1) {
+        reinterpret_cast<u32x4*>(dst + 64)[0] = u32x4{0u, 0u, 0u, 0u};
+        reinterpret_cast<u32x4*>(dst + 64)[1] = u32x4{0u, 0u, 0u, 0u};
+    }
 }
 
+template <typename Tag, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void fwd_fp8v_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
+                                                          const uint8_t* __restrict__ v8t, const float* __restrict__ sq,
+                                                          const float* __restrict__ sk, const int* __restrict__ svexp,
+                                                          uint16_t* __restrict__ o, float* __restrict__ lse, int n, int nqt,
+                                                          int nb, int ntile, float c_log2) {
+    constexpr int D = 128, BM = 256, BN = 128, KB = 4, NM = D / 32, NDV = D / 32;
+    constexpr int TILE = BN * D;                         // bytes of a K tile and of a V^T tile alike
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K8 tile | V8^T tile]
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = L / nqt;
+    int qt = L - bh * nqt;
+    if (CAUSAL) qt = nqt - 1 - qt;
+    const int q0 = qt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = q0 + 32 * w + r;
+    const size_t base = (size_t)bh * n * D;
+
+    const buf_rsrc_t q_rs = make_rsrc(q8 + base, (unsigned)n * D);
+    u32x4 qf[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) qf[m] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, qrow * D + 32 * m + 16 * h, 0, 0);
+    const int qblk = min((q0 + 32 * w) / 64, nb - 1);
+    const float fq = sq[(size_t)bh * nb + qblk] * c_log2;   // q-block scale folded with softmax_scale * log2(e)
+
+    const int kend = CAUSAL ? min(n, q0 + BM) : n;
+    const int ntiles = (kend + BN - 1) / BN;
+    const rsrc_s_t k_rs = make_rsrc_s(k8 + base, (unsigned)n * D);
+    const rsrc_s_t v_rs = make_rsrc_s(v8t + (size_t)bh * ntile * TILE, (unsigned)ntile * TILE);
+    const int voff = dma_lane_voff<64>(lane, w);         // 128-byte rows: the geometry of a 16-bit d = 64 tile
+    auto stage = [&](int buf, int t) {
+        char* b_ = smem + buf * 2 * TILE;
+        dma_stage_tile<64, BN, 8>(k_rs, b_, t * BN, voff, w);
+        dma_stage_tile<64, BN, 8>(v_rs, b_ + TILE, t * BN, voff, w);   // V^T tile t = rows 128 t .. of the [tile][d row] matrix
+    };
+
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                // running max in log2 units of the scaled score
+
+    stage(0, 0);
+    dma_wait_all();
+    __syncthreads();
+    const int ntiles_w = CAUSAL ? min(ntiles, (q0 + 32 * w + 31) / BN + 1) : ntiles;
+
+    for (int t = 0; t < ntiles_w; ++t) {
+        const int k0 = t * BN, cur = t & 1;
+        if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+        const char* Kt = smem + cur * 2 * TILE;
+        const char* Vt = Kt + TILE;
+        const size_t sb = (size_t)bh * nb;
+        const int b0 = min(2 * t, nb - 1), b1 = min(2 * t + 1, nb - 1);   // the tile's two 64-key blocks (the second may lie past N)
+        const float f0 = fq * sk[sb + b0], f1 = fq * sk[sb + b1];
+        const int e0 = svexp[sb + b0], e1 = svexp[sb + b1];
+        f32x16 sacc[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int M = 0; M < NM / 2; ++M) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 4 * M + h));
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(Kt + TileSwz<64>::off(32 * kb + r, 4 * M + 2 + h));
+                const i32x8_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                const u32x4 b0_ = qf[2 * M], b1_ = qf[2 * M + 1];
+                const i32x8_t b = {(int)b0_[0], (int)b0_[1], (int)b0_[2], (int)b0_[3], (int)b1_[0], (int)b1_[1], (int)b1_[2], (int)b1_[3]};
+                sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, sacc[kb], 0, 0, 0, 127, 0, 127);
+            }
+        }
+        const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
+        const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
+            const float f = kb < 2 ? f0 : f1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float s_ = ((i & 3) + 8 * (i >> 2) > thr) ? -INFINITY : sacc[kb][i] * f;
+                sacc[kb][i] = s_;
+                mx = fmaxf(mx, s_);
+            }
+        }
+        mx = fmaxf(mx, wave_half_swap(mx));
+        const float m_new = fmaxf(m_run, mx);
+        float m_use;
+        if (__any(m_new - m_run > 8.0f) != 0) {   // lazy rescale (fa_fwd_mfma.hip); m_run = -inf on the first tile -> true
+            m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < NDV; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[t2][i] *= alpha;
+        } else {
+            m_use = m_run;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            i32x8_t pb;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kb = 2 * g + kk;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[kb][i] - m_use);
+                    sacc[kb][i] = p;
+                    rs += p;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int wd = 0;
+                    wd = __builtin_amdgcn_cvt_pk_fp8_f32(sacc[kb][4 * j + 0], sacc[kb][4 * j + 1], wd, false);
+                    wd = __builtin_amdgcn_cvt_pk_fp8_f32(sacc[kb][4 * j + 2], sacc[kb][4 * j + 3], wd, true);
+                    pb[4 * kk + j] = wd;
+                }
+            }
+            const int se = g == 0 ? e0 : e1;
+#pragma unroll
+            for (int dvb = 0; dvb < NDV; ++dvb) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(Vt + TileSwz<64>::off(32 * dvb + r, 4 * g + h));
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(Vt + TileSwz<64>::off(32 * dvb + r, 4 * g + 2 + h));
+                const i32x8_t a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                oacc[dvb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pb, oacc[dvb], 0, 0, 0, se, 0, 127);
+            }
+        }
+        l_run += rs;
+        dma_wait_all();
+        __syncthreads();
+    }
+    for (int t = ntiles_w; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage((t & 1) ^ 1, t + 1);
+        dma_wait_all();
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + wave_half_swap(l_run);
+    if (qrow < n) {
+        const float inv = 1.f / l_tot;
+        uint16_t* orow = o + base + (size_t)qrow * D;
+#pragma unroll
+        for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
+                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * g + 4 * h) = pk;
+            }
+        if (h == 0) lse[(size_t)bh * n + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+bool fwd_fp8_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
+
+// workspace: [q8: BH*N*D bytes][k8: BH*N*D bytes][pad][sq: BH*nb floats][sk: BH*nb floats][svexp: BH*nb ints][pad]
+//            [v8t: BH * ntile * 128 * 128 bytes], nb = ceil(N/64), ntile = ceil(N/128)
+struct Fp8Ws { uint8_t *q8, *k8, *v8t; float *sq, *sk; int* svexp; size_t bytes; };
+static Fp8Ws fp8_ws_layout(void* ws, int64_t bh, int64_t n, int64_t d) {
+    const size_t nb = (size_t)((n + 63) / 64), ntile = (size_t)((n + 127) / 128), nbytes = (size_t)bh * n * d;
+    char* p = reinterpret_cast<char*>(ws);
+    Fp8Ws L;
+    L.q8 = reinterpret_cast<uint8_t*>(p);
+    L.k8 = L.q8 + nbytes;
+    size_t off = (2 * nbytes + 255) & ~(size_t)255;
+    L.sq = reinterpret_cast<float*>(p + off);
+    L.sk = L.sq + (size_t)bh * nb;
+    L.svexp = reinterpret_cast<int*>(L.sk + (size_t)bh * nb);
+    off = (off + 3 * sizeof(float) * (size_t)bh * nb + 255) & ~(size_t)255;
+    L.v8t = reinterpret_cast<uint8_t*>(p + off);
+    L.bytes = off + (size_t)bh * ntile * 128 * 128 + 256;
+    return L;
+}
+size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d) { return fp8_ws_layout(nullptr, bh, n, d).bytes; }
+
+// a.v: the kernel with the 16-bit P.V (option fp8_pv = 1) expects the ROUND-TRIPPED V there (launch_fp8_roundtrip); the
+// all-e4m3 kernel quantises a.v itself
 template <typename Tag>
 static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
     constexpr int D = 128;
-    const int nb = (int)((a.n + 63) / 64);
-    const size_t nbytes = (size_t)a.bh * a.n * D;
-    uint8_t* q8 = reinterpret_cast<uint8_t*>(ws);
-    uint8_t* k8 = q8 + nbytes;
-    float* sq = reinterpret_cast<float*>(q8 + ((2 * nbytes + 255) & ~(size_t)255));
-    float* sk = sq + (size_t)a.bh * nb;
+    const int nb = (int)((a.n + 63) / 64), ntile = (int)((a.n + 127) / 128);
+    const Fp8Ws L = fp8_ws_layout(ws, a.bh, a.n, D);
+    const bool pv16 = option(OPT_FP8_PV) == 1;
     {
         ProfScope ps(K_FP8_QUANT, st);
         if (option(OPT_FP8_ROT) == 2)   // option fp8_rot = 2: quantise without the incoherent rotation (A/B, tests)
             hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false, false>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
-                               (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
+                               (const uint16_t*)a.k, L.q8, L.k8, L.sq, L.sk, (int)a.n, nb);
         else
             hipLaunchKernelGGL((fp8_quant_kernel<Tag, D, false, true>), dim3(nb, (unsigned)a.bh, 2), dim3(256), 0, st, (const uint16_t*)a.q,
-                               (const uint16_t*)a.k, q8, k8, sq, sk, (int)a.n, nb);
+                               (const uint16_t*)a.k, L.q8, L.k8, L.sq, L.sk, (int)a.n, nb);
+        if (!pv16)
+            hipLaunchKernelGGL(fp8_quant_v_kernel<Tag>, dim3(nb, (unsigned)a.bh), dim3(256), 0, st, (const uint16_t*)a.v, L.v8t, L.svexp,
+                               (int)a.n, nb, ntile);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int nqt = (int)((a.n + 255) / 256);
-    const size_t smem = 2 * (64 * D + 64 * D * 2);
     const float c = a.scale * 1.4426950408889634f;
     dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_FP8, st);
+    if (!pv16) {
+        const size_t smem = 2 * 2 * 128 * D;
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8, (const uint8_t*)L.v8t,
+                               (const float*)L.sq, (const float*)L.sk, (const int*)L.svexp, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, ntile, c);
+            return hipGetLastError();
+        };
+        return a.causal ? launch(fwd_fp8v_kernel<Tag, true>) : launch(fwd_fp8v_kernel<Tag, false>);
+    }
+    const size_t smem = 2 * (64 * D + 64 * D * 2);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)q8, (const uint8_t*)k8, (const float*)sq,
-                           (const float*)sk, (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, c);
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8, (const float*)L.sq,
+                           (const float*)L.sk, (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, c);
         return hipGetLastError();
     };
     return a.causal ? launch(fwd_fp8_kernel<Tag, true>) : launch(fwd_fp8_kernel<Tag, false>);
 }
 
-// q, k -> their e4m3 round trip (quantise with block scales, dequantise) as 16-bit tensors qt, kt
-hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
-                                hipStream_t st) {
+// q, k, v -> their e4m3 round trips as 16-bit tensors qt, kt, vt (a null source is skipped).  Q and K are rotated around the
+// quantisation when the head dim is a power of two (option fp8_rot = 2: never), V never is.
+hipError_t launch_fp8_roundtrip(const void* q, const void* k, const void* v, void* qt, void* kt, void* vt, int64_t bh, int64_t n,
+                                int64_t d, int dtype, hipStream_t st) {
     const int nb = (int)((n + 63) / 64);
+    const bool rot = option(OPT_FP8_ROT) != 2 && (d & (d - 1)) == 0;
+    Fp8RtArgs a{};
+    int cnt = 0;
+    const void* srcs[3] = {q, k, v};
+    void* dsts[3] = {qt, kt, vt};
+    for (int i = 0; i < 3; ++i)
+        if (srcs[i]) { a.src[cnt] = (const uint16_t*)srcs[i]; a.dst[cnt] = (uint16_t*)dsts[i]; a.rot[cnt] = (i < 2 && rot) ? 1 : 0; ++cnt; }
+    if (!cnt || bh <= 0 || n <= 0) return hipSuccess;
     ProfScope ps(K_FP8_QUANT, st);
-    auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(nb, (unsigned)bh, 2), dim3(256), 0, st, (const uint16_t*)q, (const uint16_t*)k, (uint8_t*)qt,
-                           (uint8_t*)kt, (float*)nullptr, (float*)nullptr, (int)n, nb);
-    };
-    const bool rot = option(OPT_FP8_ROT) != 2;
-    if (dtype == 2) { if (rot) go(fp8_quant_kernel<bf16_tag, 128, true, true>); else go(fp8_quant_kernel<bf16_tag, 128, true, false>); }
-    else { if (rot) go(fp8_quant_kernel<f16_tag, 128, true, true>); else go(fp8_quant_kernel<f16_tag, 128, true, false>); }
+    if (dtype == 2) hipLaunchKernelGGL(fp8_roundtrip_kernel<bf16_tag>, dim3(nb, (unsigned)bh, cnt), dim3(256), 0, st, a, (int)n, (int)d);
+    else hipLaunchKernelGGL(fp8_roundtrip_kernel<f16_tag>, dim3(nb, (unsigned)bh, cnt), dim3(256), 0, st, a, (int)n, (int)d);
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ hipError_t ensure_dynamic_smem(const void* kernel, int bytes);
 // Tuning knobs (tile sweep / A-B runs).  Each starts from an environment variable of the same upper-case name with
 // an FA_ prefix (FA_FWD_KB, FA_FWD_STAG, FA_DKDV (4|8), FA_DQ_KT, FA_FWD_RS, FA_DKDV_KREG, FA_FWD_EAGER, FA_FWD_HS, FA_FWD_TPW, FA_DQ_TPW, FA_DKDV_TPW, FA_DQ_NLF, FA_DQ_W4, FA_FWD_ABL, FA_SMALL_GRID, FA_FP8_ROT, FA_DKDV_STG) and can be changed at run time through
 // fa_set_option() so that variants can be interleaved in one process.
-enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_DS_CHUNK_MB, OPT_COUNT };
+enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_DS_CHUNK_MB, OPT_FP8_PV, OPT_COUNT };
 int option(int id);
 int set_option(const char* name, int value);   // returns 0, or -1 for an unknown name
 
@@ -96,8 +96,10 @@ hipError_t launch_bwd_dq_w4(const BwdArgs& a, float* nlse, float* ndelta, hipStr
 bool fwd_fp8_supported(int dtype, int64_t d);
 hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st);
 size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
-hipError_t launch_fp8_roundtrip(const void* q, const void* k, void* qt, void* kt, int64_t bh, int64_t n, int dtype,
-                                hipStream_t st);
+// e4m3 round trip (one scale per 64-row block) of q, k (rotated around the quantisation for power-of-two d) and v into 16-bit
+// tensors, any d % 8 == 0 up to 256; null sources are skipped
+hipError_t launch_fp8_roundtrip(const void* q, const void* k, const void* v, void* qt, void* kt, void* vt, int64_t bh, int64_t n,
+                                int64_t d, int dtype, hipStream_t st);
 
 // Extended attention: Nq != Nk with a bottom-right aligned causal mask, dense mask, block-sparse mask, dropout.
 // fa_ex.hip: exact-f32 kernels, any dtype, d <= 256.  fa_ex_mfma.hip: bf16 / f16, d % 8 == 0 up to 128, block-sparse

@@ -57,6 +57,8 @@ __all__ = [
     "block_absmax_scale",
     "quantize_e4m3_blockwise",
     "fp8_attention",
+    "fp8_attention_backward",
+    "fp8_roundtrip",
     "attention_flops",
 ]
 
@@ -269,23 +271,66 @@ def incoherent_rotate(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return ((xf * s) @ h) / math.sqrt(d)
 
 
-def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k, rotate: bool = True):
-    """Attention with Q and K quantised to e4m3 per row block, V and P kept in 16/32-bit.
+def quantize_e4m3_blockwise_pow2(x: torch.Tensor, block: int):
+    """As `quantize_e4m3_blockwise` with the scale rounded UP to a power of two (2^e >= absmax / 448): the form the block-scaled
+    MFMA applies by itself (E8M0 scale operand), used for V by the all-e4m3 kernel (csrc/fa_fwd_fp8.hip: fp8_quant_v_kernel)."""
+    amax = block_absmax_scale(x, block)
+    scale = torch.exp2(torch.ceil(torch.log2(amax.double() / E4M3_MAX))).float()
+    xq = torch.empty(x.shape, dtype=torch.float32)
+    for i in range(amax.shape[1]):
+        sl = slice(i * block, min((i + 1) * block, x.shape[1]))
+        xq[:, sl] = (x[:, sl].float() / scale[:, i, None, None]).to(torch.float8_e4m3fn).float()
+    return xq, scale
 
-    This is the numerical model of the HIP `fa3_forward(fp8=True)` path: Q and K are first rotated by
-    `incoherent_rotate` (rotate=False: the library's option fp8_rot=2), then quantised.
-    """
-    if rotate:
-        q, k = incoherent_rotate(q), incoherent_rotate(k)
-    qq, sq = quantize_e4m3_blockwise(q, block_q)
-    kq, sk = quantize_e4m3_blockwise(k, block_k)
-    n = q.shape[1]
-    rq = torch.repeat_interleave(sq, block_q, dim=1)[:, :n]
-    rk = torch.repeat_interleave(sk, block_k, dim=1)[:, :n]
-    qd = qq * rq[..., None]
-    kd = kq * rk[..., None]
-    o, lse = exact_attention(qd, kd, v.float(), causal, softmax_scale)
-    return o.to(v.dtype), lse
+
+def fp8_roundtrip(q, k, v, block_q, block_k, rotate: bool = True, quantize_v: bool = True, v_pow2: bool = False):
+    """(Q~, K~, V~): what the e4m3 path computes attention OF — each tensor quantised to e4m3 with one absmax scale per row
+    block and dequantised (fp32 results).  Q and K are rotated by `incoherent_rotate` around the quantisation when the head dim
+    is a power of two (the reference skips its rotation otherwise too, src/fa3/torch/impl.py:60-61) and rotated back, which
+    leaves Q~ K~^T what the rotated tensors give: (Q^ R^T)(K^ R^T)^T = Q^ K^^T.  V is quantised as it is
+    (src/fa3/torch/impl.py:125-131: sv / vb2).  rotate=False: the library's option fp8_rot = 2."""
+    d = q.shape[-1]
+    rot = rotate and (d & (d - 1)) == 0
+
+    def rt(x, block, r, pow2=False):
+        xr = incoherent_rotate(x) if r else x.float()
+        xq, sc = (quantize_e4m3_blockwise_pow2 if pow2 else quantize_e4m3_blockwise)(xr, block)
+        y = xq * torch.repeat_interleave(sc, block, dim=1)[:, : x.shape[1], None]
+        return incoherent_rotate(y, inverse=True) if r else y
+
+    return rt(q, block_q, rot), rt(k, block_k, rot), (rt(v, block_k, False, v_pow2) if quantize_v else v.float())
+
+
+def fp8_attention(q, k, v, causal, softmax_scale, block_q, block_k, rotate: bool = True, quantize_v: bool = True,
+                  p_e4m3: bool = False):
+    """Attention with Q, K and V quantised to e4m3 per row block; the numerical model of the HIP `fa3_forward(fp8=True)` path.
+    p_e4m3=False: P and the accumulation in fp32 — the path whose P.V product is 16-bit (every head dim but 128, and option
+    fp8_pv = 1 there).  p_e4m3=True: the all-e4m3 kernel (d = 128 default): V with a power-of-two block scale and the
+    probabilities p = exp(s - rowmax) rounded to e4m3 in the P.V product, the row sum (and lse) from the unrounded p.  (The
+    kernel rounds p relative to a running maximum that may lag the true one by up to 2^8, so its roundings differ from these
+    element by element; the model has the same error statistics, not the same bits.)
+    This is this repo's model of the reference's INTENT (its own fp8 branch models no 8-bit rounding and its rotation is not
+    orthogonal: SURVEY D6, D7) — fp8 parity is not pinned by a reference fixture."""
+    qd, kd, vd = fp8_roundtrip(q, k, v, block_q, block_k, rotate, quantize_v, v_pow2=p_e4m3)
+    if not p_e4m3:
+        o, lse = exact_attention(qd, kd, vd, causal, softmax_scale)
+        return o.to(v.dtype), lse
+    s = torch.matmul(qd.double(), kd.double().transpose(-2, -1)) * softmax_scale
+    if causal:
+        s = s.masked_fill(_causal_mask(s.shape[-2], s.shape[-1], s.device)[None], float("-inf"))
+    m = s.amax(dim=-1, keepdim=True)
+    p = torch.exp(s - m)
+    p8 = p.float().to(torch.float8_e4m3fn).double()
+    o = torch.matmul(p8, vd.double()) / p.sum(dim=-1, keepdim=True)
+    lse = (m.squeeze(-1) + torch.log(p.sum(dim=-1))).float()
+    return o.float().to(v.dtype), lse
+
+
+def fp8_attention_backward(q, k, v, dout, causal, softmax_scale, block_q, block_k, rotate: bool = True, quantize_v: bool = True):
+    """(dq, dk, dv, o, lse) of the function `fp8_attention` evaluates, taken at the round-tripped tensors and handed to q, k, v
+    themselves (straight-through over the rounding), as the reference's fa3_backward does (csrc/fa3/fa3_bwd.cu:134-146)."""
+    qd, kd, vd = fp8_roundtrip(q, k, v, block_q, block_k, rotate, quantize_v)
+    return exact_attention_backward(qd, kd, vd, dout, causal, softmax_scale, math_dtype=torch.float64)
 
 
 # --------------------------------------------------------------------------- FLOP accounting

@@ -465,14 +465,23 @@ def test_every_selectable_kernel_variant_matches_the_oracle(opts, causal, device
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_fa3_fp8_forward_and_backward(causal, dtype, device):
-    """FA3 fp8=True at d=128: Q/K go through real e4m3 with 64-row block scales.  Checked against the oracle's e4m3
-    model (tight: same quantisation) and against the exact result at the reference's fp8 bar 1e-1
-    (tests/test_correctness_fa3.py:31-32,89); the backward differentiates the quantised function (e4m3 round trip of Q, K)."""
-    bh, n, d = 2, 333, 128
-    q, k, v, do = make_qkv(bh, n, d, dtype, seed=31)
+@pytest.mark.parametrize("bh,n,d", [(2, 333, 128), (2, 200, 64), (2, 32, 32), (3, 150, 40), (1, 300, 256), (2, 96, 16)])
+def test_fa3_fp8_forward_and_backward(bh, n, d, causal, dtype, device):
+    """FA3 fp8=True: Q, K AND V go through real e4m3 with 64-row block scales (the reference's wiring quantises all three,
+    csrc/fa3/fa3_fwd.cu:196-208) at every head dim the 16-bit kernels take — d = 128 on the e4m3 MFMA kernel, the others (among
+    them the reference's own fp8 test shape 2 x 32 x 32, tests/test_correctness_fa3.py:74, and d = 40, where neither side
+    rotates) as a round trip ahead of the 16-bit kernels.  Checked against the oracle's e4m3 model (tight: same quantisation)
+    and against the exact result at the reference's fp8 bar 1e-1 (tests/test_correctness_fa3.py:31-32,89); the backward
+    differentiates the quantised function (round trip of Q, K, V) — against the model's gradients and the exact ones."""
+    import flashattention_lab_cuda as ext
+
+    q, k, v, do = make_qkv(bh, n, d, dtype, seed=31 + d)
     scale = d ** -0.5
-    o, lse, dq, dk, dv = _run(3, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device), fp8=True)
+    ext.set_option("fp8_pv", 1)   # d = 128: the variant whose P stays 16-bit, which is what this model describes
+    try:
+        o, lse, dq, dk, dv = _run(3, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device), fp8=True)
+    finally:
+        ext.set_option("fp8_pv", 0)
     mo, mlse = orc.fp8_attention(q, k, v, causal, scale, 64, 64)
     torch.testing.assert_close(o.cpu().float(), mo.float(), rtol=2e-2, atol=2e-2)
     assert max_abs(lse.cpu(), mlse) < 2e-2
@@ -480,14 +489,65 @@ def test_fa3_fp8_forward_and_backward(causal, dtype, device):
     torch.testing.assert_close(o.cpu().float(), ro.float(), rtol=1e-1, atol=1e-1)
     o16, _ = _run(3, q.to(device), k.to(device), v.to(device), causal, scale, fp8=False)
     assert not torch.equal(o16, o)  # the e4m3 path really ran
+    mq, mk, mv, _, _ = orc.fp8_attention_backward(q, k, v, do, causal, scale, 64, 64)
+    for a, b, m in ((dq, rq, mq), (dk, rk, mk), (dv, rv, mv)):
+        assert a.dtype == dtype
+        torch.testing.assert_close(a.cpu().float(), b.float(), rtol=1e-1, atol=1e-1)
+        torch.testing.assert_close(a.cpu().float(), m.float(), rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bh,n", [(2, 333), (2, 1000), (1, 128), (3, 64), (1, 2100)])
+def test_fa3_fp8_all_e4m3_kernel_at_d128(bh, n, causal, dtype, device):
+    """The default at d = 128: S AND P.V on the block-scaled e4m3 MFMA (V transposed, key-permuted, power-of-two block scales
+    applied by the instruction; P in e4m3).  Against the oracle's model of it (same error statistics, not the same bits: the
+    kernel rounds p relative to a lagging maximum), against the exact result at the reference's fp8 bar, lse (which never
+    sees the 8-bit P) tightly against the model; ragged N, odd 64-key block counts (N = 64, 333, 2100), several tiles."""
+    d = 128
+    q, k, v, do = make_qkv(bh, n, d, dtype, seed=900 + n)
+    scale = d ** -0.5
+    o, lse, dq, dk, dv = _run(3, q.to(device), k.to(device), v.to(device), causal, scale, do=do.to(device), fp8=True)
+    mo, mlse = orc.fp8_attention(q, k, v, causal, scale, 64, 64, p_e4m3=True)
+    assert torch.isfinite(o.float()).all()
+    torch.testing.assert_close(o.cpu().float(), mo.float(), rtol=8e-2, atol=8e-2)
+    assert (o.cpu().float() - mo.float()).abs().mean().item() < 4e-3      # and on average far inside that
+    assert max_abs(lse.cpu(), mlse) < 2e-2
+    rq, rk, rv, ro, rlse = orc.exact_attention_backward(q, k, v, do, causal, scale, math_dtype=torch.float64)
+    torch.testing.assert_close(o.cpu().float(), ro.float(), rtol=1e-1, atol=1e-1)
     for a, b in ((dq, rq), (dk, rk), (dv, rv)):
         torch.testing.assert_close(a.cpu().float(), b.float(), rtol=1e-1, atol=1e-1)
 
 
+def test_fa3_fp8_quantises_v(device):
+    """V really goes through e4m3: with one huge element per 64-row block of V the block's scale swallows the small ones
+    (the result then follows the model with V quantised, not the one without)."""
+    bh, n, d = 2, 256, 64
+    q, k, v, _ = make_qkv(bh, n, d, torch.bfloat16, seed=77)
+    v[:, ::64, 0] = 3000.0
+    o, lse = _run(3, q.to(device), k.to(device), v.to(device), False, d ** -0.5, fp8=True)
+    with_v, _ = orc.fp8_attention(q, k, v, False, d ** -0.5, 64, 64, quantize_v=True)
+    without_v, _ = orc.fp8_attention(q, k, v, False, d ** -0.5, 64, 64, quantize_v=False)
+    sl = (slice(None), slice(None), slice(1, None))     # away from the spiked column
+    e_with = max_abs(o.cpu()[sl], with_v[sl])
+    e_without = max_abs(o.cpu()[sl], without_v[sl])
+    assert e_with < 0.05 and e_without > 4 * e_with, (e_with, e_without)
+
+
+def test_fa3_fp8_flag_is_ignored_for_fp32_tensors(device):
+    q, k, v, do = (t.to(device) for t in make_qkv(2, 50, 32, torch.float32, seed=8))
+    a = _run(3, q, k, v, True, 32 ** -0.5, do=do, fp8=True)
+    b = _run(3, q, k, v, True, 32 ** -0.5, do=do, fp8=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("pv", [0, 1], ids=["all-e4m3", "pv16"])
 @pytest.mark.parametrize("rot", [0, 2], ids=["rotated", "plain"])
-def test_fa3_fp8_incoherent_rotation_against_its_model(rot, device):
+def test_fa3_fp8_incoherent_rotation_against_its_model(rot, pv, device):
     """The sign + Hadamard rotation ahead of the e4m3 quantisation (option fp8_rot: 0 = on, 2 = off): each setting must
-    match the oracle's model of it, and with an outlier channel in Q and K the rotated path must be the more accurate."""
+    match the oracle's model of it, and with an outlier channel in Q and K the rotated path must be the more accurate.
+    Both d = 128 kernels: the all-e4m3 one (default) and the one with the 16-bit P.V (option fp8_pv = 1)."""
     import flashattention_lab_cuda as ext
 
     bh, n, d = 2, 400, 128
@@ -496,33 +556,26 @@ def test_fa3_fp8_incoherent_rotation_against_its_model(rot, device):
     k[..., 7] *= 30.0
     scale = d ** -0.5
     ext.set_option("fp8_rot", rot)
+    ext.set_option("fp8_pv", pv)
     try:
         o, lse, dq, dk, dv = _run(3, q.to(device), k.to(device), v.to(device), False, scale, do=do.to(device), fp8=True)
     finally:
         ext.set_option("fp8_rot", 0)
-    mo, mlse = orc.fp8_attention(q, k, v, False, scale, 64, 64, rotate=(rot == 0))
-    torch.testing.assert_close(o.cpu().float(), mo.float(), rtol=3e-2, atol=3e-2)
+        ext.set_option("fp8_pv", 0)
+    mo, mlse = orc.fp8_attention(q, k, v, False, scale, 64, 64, rotate=(rot == 0), p_e4m3=(pv == 0))
+    tol = 3e-2 if pv else 6e-2
+    torch.testing.assert_close(o.cpu().float(), mo.float(), rtol=tol, atol=tol)
+    assert max_abs(lse.cpu(), mlse) < 3e-2
     ro, _ = orc.exact_attention(q.double(), k.double(), v.double(), False, scale)
     err = (o.cpu().double() - ro).abs().max().item()
-    test_fa3_fp8_incoherent_rotation_against_its_model.err[rot] = err
+    errs = test_fa3_fp8_incoherent_rotation_against_its_model.err
+    errs[(rot, pv)] = err
     assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
-    if len(test_fa3_fp8_incoherent_rotation_against_its_model.err) == 2:
-        e = test_fa3_fp8_incoherent_rotation_against_its_model.err
-        assert e[0] < e[2], f"rotation did not help: {e}"
+    if (0, pv) in errs and (2, pv) in errs:
+        assert errs[(0, pv)] < errs[(2, pv)], f"rotation did not help: {errs}"
 
 
 test_fa3_fp8_incoherent_rotation_against_its_model.err = {}
-
-
-def test_fa3_fp8_flag_on_shapes_without_an_fp8_kernel_takes_the_regular_path(device):
-    # the reference's own fp8 test shape: (1,2,32,32) fp16 — tests/test_correctness_fa3.py:74
-    q, k, v, do = (t.to(device) for t in make_qkv(2, 32, 32, torch.float16, seed=22))
-    a = _run(3, q, k, v, True, 32 ** -0.5, do=do, fp8=True)
-    b = _run(3, q, k, v, True, 32 ** -0.5, do=do, fp8=False)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    ro, rlse = orc.exact_attention(q.cpu(), k.cpu(), v.cpu(), True, 32 ** -0.5)
-    torch.testing.assert_close(a[0].cpu(), ro, rtol=1e-1, atol=1e-1)
 
 
 def test_fa3_fp8_config5_shape_runs(device):
@@ -533,7 +586,7 @@ def test_fa3_fp8_config5_shape_runs(device):
     o, lse = _run(3, q.to(device), k.to(device), v.to(device), False, d ** -0.5, fp8=True)
     o2, lse2 = _run(3, q.to(device), k.to(device), v.to(device), False, d ** -0.5, fp8=True)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
-    mo, mlse = orc.fp8_attention(q[:1, :].float(), k[:1].float(), v[:1].float(), False, d ** -0.5, 64, 64)
+    mo, mlse = orc.fp8_attention(q[:1, :].float(), k[:1].float(), v[:1].float(), False, d ** -0.5, 64, 64, p_e4m3=True)
     torch.testing.assert_close(o[:1].cpu().float(), mo, rtol=2e-2, atol=2e-2)
     assert max_abs(lse[:1].cpu(), mlse) < 2e-2
 
@@ -556,7 +609,7 @@ def test_fa3_fp8_config5_forward_and_backward_at_full_size(device):
             assert torch.equal(t[:u], t[c * u:(c + 1) * u])
     o16, _ = _run(3, qd[:1], kd[:1], vd[:1], False, scale, fp8=False)
     assert not torch.equal(o16[0], o[0])   # the e4m3 path really ran
-    mo, mlse = orc.fp8_attention(q[:1].float(), k[:1].float(), v[:1].float(), False, scale, 64, 64)
+    mo, mlse = orc.fp8_attention(q[:1].float(), k[:1].float(), v[:1].float(), False, scale, 64, 64, p_e4m3=True)
     torch.testing.assert_close(o[:1].cpu().float(), mo, rtol=2e-2, atol=2e-2)
     assert max_abs(lse[:1].cpu(), mlse) < 2e-2
     lhs, rhs = dv[:u].float().sum(dim=1), dod[:u].float().sum(dim=1)
