@@ -283,12 +283,8 @@ int fa3_forward(const void* q, const void* k, const void* v, void* o, float* lse
         if (fa::fwd_fp8_supported(dtype, d)) {
             // d = 128: [V~][the e4m3 kernels' own workspace: Q, K, V^T bytes and scales].  Default: S and P.V on the e4m3 MFMA;
             // option fp8_pv = 1: S on the e4m3 MFMA, P.V 16-bit on the round-tripped V.
-            const bool pv16 = fa::option(fa::OPT_FP8_PV) == 1;
-            e = pv16 ? fa::launch_fp8_roundtrip(nullptr, nullptr, v, nullptr, nullptr, ws, bh, n, d, dtype, st) : hipSuccess;
-            if (e == hipSuccess) {
-                fa::FwdArgs a{q, k, pv16 ? (const void*)ws : v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
-                e = fa::launch_fwd_fp8(a, ws + slab, st);
-            }
+            fa::FwdArgs a{q, k, v, o, lse, bh, n, d, dtype, causal ? 1 : 0, (float)softmax_scale};
+            e = fa::launch_fwd_fp8(a, ws + slab, ws, st);
         } else {
             // [Q~][K~][V~] (original basis), then the 16-bit kernels as they are
             e = fa::launch_fp8_roundtrip(q, k, v, ws, ws + slab, ws + 2 * slab, bh, n, d, dtype, st);

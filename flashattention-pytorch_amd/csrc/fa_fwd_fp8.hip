@@ -136,9 +136,8 @@ struct Fp8RtArgs {
     uint16_t* dst[3];
     int rot[3];
 };
-template <typename Tag>
+template <typename Tag, int MAXI>               // MAXI: 16-byte chunks per thread = ceil(64 rows x d / 8 chunks / 256 threads): 1, 2, 4, 8
 __global__ __launch_bounds__(256) void fp8_roundtrip_kernel(Fp8RtArgs a, int n, int d) {
-    constexpr int MAXI = 8;                     // 64 rows x 32 chunks (d = 256) over 256 threads
     __shared__ float red[4];
     const int z = blockIdx.z, bh = blockIdx.y, row0 = blockIdx.x * 64;
     const uint16_t* src = a.src[z];
@@ -393,7 +392,11 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8_kernel(const uint8_t* __restri
 //   * one V scale per 64-key block that the MFMA can apply itself: a power of two (2^e >= absmax / 448), handed to the
 //     instruction as the E8M0 block scale of its A operand.  Keys past N are written as zeros (their P is 0: 0 x 0).
 //   * P in e4m3: p = exp2(s - m) lies in (0, 256] under the lazy rescale, inside e4m3's range (448); the row sum and lse come
-//     from the f32 p, so only O sees the 3-bit mantissa (about 1e-2 absolute at N = 16384, inside the reference's 1e-1 bar).
+//     from the f32 p, so only O sees the 3-bit mantissa — 2^-4 relative per probability, which averages out over the keys of a
+//     row: harmless from a few dozen keys on, up to 6 % of |v| on a row that sees two.  Rows that short exist only in the FIRST
+//     query tile under the causal mask (every later tile's rows see >= 256 keys) and on problems of N <= 256: those run on the
+//     kernel above with its 16-bit P (launch_fp8_t), so that o stays what the backward — which recomputes P exactly from lse —
+//     differentiates (the delta = rowsum(dO o) it takes from the forward's o otherwise puts the same 6 % into dQ).
 template <typename Tag>
 __global__ __launch_bounds__(256) void fp8_quant_v_kernel(const uint16_t* __restrict__ v, uint8_t* __restrict__ v8t,
                                                           int* __restrict__ svexp, int n, int nb, int ntile) {
@@ -456,15 +459,15 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8v_kernel(const uint8_t* __restr
                                                           const uint8_t* __restrict__ v8t, const float* __restrict__ sq,
                                                           const float* __restrict__ sk, const int* __restrict__ svexp,
                                                           uint16_t* __restrict__ o, float* __restrict__ lse, int n, int nqt,
-                                                          int nb, int ntile, float c_log2) {
+                                                          int nb, int ntile, float c_log2, int nqt_run /* query tiles this launch covers: under the causal mask tiles nqt - 1 .. nqt - nqt_run */) {
     constexpr int D = 128, BM = 256, BN = 128, KB = 4, NM = D / 32, NDV = D / 32;
     constexpr int TILE = BN * D;                         // bytes of a K tile and of a V^T tile alike
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K8 tile | V8^T tile]
     typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nqt;
-    int qt = L - bh * nqt;
+    const int bh = L / nqt_run;
+    int qt = L - bh * nqt_run;
     if (CAUSAL) qt = nqt - 1 - qt;
     const int q0 = qt * BM;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -526,20 +529,26 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8v_kernel(const uint8_t* __restr
                 sacc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, sacc[kb], 0, 0, 0, 127, 0, 127);
             }
         }
+        // mask and row maximum on the RAW products (the block scales f0, f1 > 0 are applied to the two maxima, and to every
+        // element inside the exp2 argument's fma: one vector instruction per element less than scaling first)
         const bool need_mask = (CAUSAL && (k0 + BN - 1 > q0 + 32 * w)) || (k0 + BN > n);
         const int lim = CAUSAL ? min(qrow, n - 1) : n - 1;
-        float mx = -INFINITY;
+        float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            const int thr = need_mask ? lim - (k0 + 32 * kb + 4 * h) : 64;
-            const float f = kb < 2 ? f0 : f1;
+            if (need_mask) {
+                const int thr = lim - (k0 + 32 * kb + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((i & 3) + 8 * (i >> 2) > thr) sacc[kb][i] = -INFINITY;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float s_ = ((i & 3) + 8 * (i >> 2) > thr) ? -INFINITY : sacc[kb][i] * f;
-                sacc[kb][i] = s_;
-                mx = fmaxf(mx, s_);
+                if (kb < 2) mx0 = fmaxf(mx0, sacc[kb][i]);
+                else mx1 = fmaxf(mx1, sacc[kb][i]);
             }
         }
+        float mx = fmaxf(mx0 * f0, mx1 * f1);
         mx = fmaxf(mx, wave_half_swap(mx));
         const float m_new = fmaxf(m_run, mx);
         float m_use;
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8v_kernel(const uint8_t* __restr
                 const int kb = 2 * g + kk;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[kb][i] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], g == 0 ? f0 : f1, -m_use));   // (-inf stays -inf: f > 0)
                     sacc[kb][i] = p;
                     rs += p;
                 }
@@ -634,14 +643,18 @@ static Fp8Ws fp8_ws_layout(void* ws, int64_t bh, int64_t n, int64_t d) {
 }
 size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d) { return fp8_ws_layout(nullptr, bh, n, d).bytes; }
 
-// a.v: the kernel with the 16-bit P.V (option fp8_pv = 1) expects the ROUND-TRIPPED V there (launch_fp8_roundtrip); the
-// all-e4m3 kernel quantises a.v itself
+// Q and K -> e4m3 bytes + scales; then the all-e4m3 kernel (V quantised transposed) or, with option fp8_pv = 1, the kernel with
+// the 16-bit P.V on the round-tripped V (`vslab`: room for one 16-bit tensor).  Under the causal mask the first query tile, and
+// problems of N <= 256 altogether, take the 16-bit P.V in either case (see the comment above fp8_quant_v_kernel).
 template <typename Tag>
-static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
+static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, void* vslab, hipStream_t st) {
     constexpr int D = 128;
     const int nb = (int)((a.n + 63) / 64), ntile = (int)((a.n + 127) / 128);
+    const int nqt = (int)((a.n + 255) / 256);
     const Fp8Ws L = fp8_ws_layout(ws, a.bh, a.n, D);
-    const bool pv16 = option(OPT_FP8_PV) == 1;
+    const bool pv16 = option(OPT_FP8_PV) == 1 || a.n <= 256;
+    const int nqt16 = pv16 ? nqt : (a.causal ? 1 : 0);          // query tiles on the 16-bit P.V kernel (the first ones)
+    const int64_t vrows = pv16 ? a.n : (a.causal ? (a.n < 256 ? a.n : 256) : 0);   // rows of V they read
     {
         ProfScope ps(K_FP8_QUANT, st);
         if (option(OPT_FP8_ROT) == 2)   // option fp8_rot = 2: quantise without the incoherent rotation (A/B, tests)
@@ -653,33 +666,43 @@ static hipError_t launch_fp8_t(const FwdArgs& a, void* ws, hipStream_t st) {
         if (!pv16)
             hipLaunchKernelGGL(fp8_quant_v_kernel<Tag>, dim3(nb, (unsigned)a.bh), dim3(256), 0, st, (const uint16_t*)a.v, L.v8t, L.svexp,
                                (int)a.n, nb, ntile);
+        if (vrows > 0) {   // V~ (the first `vrows` rows of every (b,h)) for the 16-bit P.V kernel
+            Fp8RtArgs r{};
+            r.src[0] = (const uint16_t*)a.v; r.dst[0] = (uint16_t*)vslab; r.rot[0] = 0;
+            hipLaunchKernelGGL((fp8_roundtrip_kernel<Tag, 4>), dim3((unsigned)((vrows + 63) / 64), (unsigned)a.bh, 1), dim3(256), 0, st, r, (int)a.n, D);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int nqt = (int)((a.n + 255) / 256);
     const float c = a.scale * 1.4426950408889634f;
-    dim3 grid((unsigned)(nqt * a.bh));
     ProfScope ps(K_FWD_FP8, st);
-    if (!pv16) {
-        const size_t smem = 2 * 2 * 128 * D;
+    if (nqt16 > 0) {
+        const size_t smem = 2 * (64 * D + 64 * D * 2);
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
             if (e2 != hipSuccess) return e2;
-            hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8, (const uint8_t*)L.v8t,
-                               (const float*)L.sq, (const float*)L.sk, (const int*)L.svexp, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, ntile, c);
+            // (nqt16 < nqt only under the causal mask: the kernel then maps its blocks to tiles nqt16 - 1 .. 0)
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nqt16 * a.bh)), dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8,
+                               (const float*)L.sq, (const float*)L.sk, (const uint16_t*)vslab, (uint16_t*)a.o, a.lse, (int)a.n, nqt16, nb, c);
             return hipGetLastError();
         };
-        return a.causal ? launch(fwd_fp8v_kernel<Tag, true>) : launch(fwd_fp8v_kernel<Tag, false>);
+        e = a.causal ? launch(fwd_fp8_kernel<Tag, true>) : launch(fwd_fp8_kernel<Tag, false>);
+        if (e != hipSuccess) return e;
     }
-    const size_t smem = 2 * (64 * D + 64 * D * 2);
-    auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
-        if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8, (const float*)L.sq,
-                           (const float*)L.sk, (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, nb, c);
-        return hipGetLastError();
-    };
-    return a.causal ? launch(fwd_fp8_kernel<Tag, true>) : launch(fwd_fp8_kernel<Tag, false>);
+    if (nqt16 < nqt) {
+        const size_t smem = 2 * 2 * 128 * D;
+        const int nrun = nqt - nqt16;
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e2 = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nrun * a.bh)), dim3(512), smem, st, (const uint8_t*)L.q8, (const uint8_t*)L.k8,
+                               (const uint8_t*)L.v8t, (const float*)L.sq, (const float*)L.sk, (const int*)L.svexp, (uint16_t*)a.o, a.lse,
+                               (int)a.n, nqt, nb, ntile, c, nrun);
+            return hipGetLastError();
+        };
+        e = a.causal ? launch(fwd_fp8v_kernel<Tag, true>) : launch(fwd_fp8v_kernel<Tag, false>);
+    }
+    return e;
 }
 
 // q, k, v -> their e4m3 round trips as 16-bit tensors qt, kt, vt (a null source is skipped).  Q and K are rotated around the
@@ -696,13 +719,14 @@ hipError_t launch_fp8_roundtrip(const void* q, const void* k, const void* v, voi
         if (srcs[i]) { a.src[cnt] = (const uint16_t*)srcs[i]; a.dst[cnt] = (uint16_t*)dsts[i]; a.rot[cnt] = (i < 2 && rot) ? 1 : 0; ++cnt; }
     if (!cnt || bh <= 0 || n <= 0) return hipSuccess;
     ProfScope ps(K_FP8_QUANT, st);
-    if (dtype == 2) hipLaunchKernelGGL(fp8_roundtrip_kernel<bf16_tag>, dim3(nb, (unsigned)bh, cnt), dim3(256), 0, st, a, (int)n, (int)d);
-    else hipLaunchKernelGGL(fp8_roundtrip_kernel<f16_tag>, dim3(nb, (unsigned)bh, cnt), dim3(256), 0, st, a, (int)n, (int)d);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb, (unsigned)bh, cnt), dim3(256), 0, st, a, (int)n, (int)d); };
+    if (dtype == 2) { if (d <= 32) go(fp8_roundtrip_kernel<bf16_tag, 1>); else if (d <= 64) go(fp8_roundtrip_kernel<bf16_tag, 2>); else if (d <= 128) go(fp8_roundtrip_kernel<bf16_tag, 4>); else go(fp8_roundtrip_kernel<bf16_tag, 8>); }
+    else { if (d <= 32) go(fp8_roundtrip_kernel<f16_tag, 1>); else if (d <= 64) go(fp8_roundtrip_kernel<f16_tag, 2>); else if (d <= 128) go(fp8_roundtrip_kernel<f16_tag, 4>); else go(fp8_roundtrip_kernel<f16_tag, 8>); }
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st) {
-    return a.dtype == 2 ? launch_fp8_t<bf16_tag>(a, workspace, st) : launch_fp8_t<f16_tag>(a, workspace, st);
+hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, void* vslab, hipStream_t st) {
+    return a.dtype == 2 ? launch_fp8_t<bf16_tag>(a, workspace, vslab, st) : launch_fp8_t<f16_tag>(a, workspace, vslab, st);
 }
 
 }  // namespace fa

@@ -94,7 +94,8 @@ hipError_t launch_bwd_dq_w4(const BwdArgs& a, float* nlse, float* ndelta, hipStr
 
 // FA3-style fp8 forward (fa_fwd_fp8.hip): Q/K quantised to e4m3 per 64-row block, S on the fp8 MFMA
 bool fwd_fp8_supported(int dtype, int64_t d);
-hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, hipStream_t st);
+// workspace: fwd_fp8_workspace_bytes; vslab: room for one 16-bit (bh, n, d) tensor (the round-tripped V of the 16-bit P.V kernel)
+hipError_t launch_fwd_fp8(const FwdArgs& a, void* workspace, void* vslab, hipStream_t st);
 size_t fwd_fp8_workspace_bytes(int64_t bh, int64_t n, int64_t d);
 // e4m3 round trip (one scale per 64-row block) of q, k (rotated around the quantisation for power-of-two d) and v into 16-bit
 // tensors, any d % 8 == 0 up to 256; null sources are skipped
