@@ -355,7 +355,7 @@ hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tra
 // lgkmcnt waits fused to each MFMA, P.V and S accumulation chains interleaved.  K and V are triple buffered with the
 // LDS-DMA issued two tiles ahead at even global half-steps g = 2u (K(u+2), V(u+1)) and counted vmcnt waits, so a
 // transfer has four half-steps to land.
-template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false>
+template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false, int RD = 4>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -500,23 +500,23 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
                 for (int j = 0; j < 4; ++j) pp[kb][s][j] = pack2<Tag>(sacc[kb][8 * s + 2 * j], sacc[kb][8 * s + 2 * j + 1]);
     };
     // lane-constant operand addresses (LDS bytes, buffer 0 of K / V); rows advance through the immediate offset: the
-    // swizzle depends on the row modulo 16 only, so +32 kb (+16 s) rows is a constant number of bytes
-    unsigned ka[NKS], vlo[NDV], vhi[NDV];
+    // swizzle depends on the row modulo 16 only, so +32 kb (+16 s) rows is a constant number of bytes.  ONE base per operand
+    // kind: the k-step / d-block enters the chunk index through disjoint bits, chunk ^ f(row) = (2 ks) ^ (h ^ f) and
+    // (4 dvb) ^ (...), and the tile bases are multiples of the row pitch, so the other addresses are the base XOR a constant
+    // (made per phase, one v_xor each, where the buffer offset used to be added) — 16 registers less than an address array
+    // per kind, which is what pays for the deeper operand ring (RD).
+    unsigned ka0, vlo0, vhi0;
     {
         const unsigned k0a = lds_addr_of(Kbuf), v0a = lds_addr_of(Vbuf);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) ka[ks] = k0a + TileSwz<D>::off(r, 2 * ks + h);
-#pragma unroll
-        for (int dvb = 0; dvb < NDV; ++dvb) {
-            const int ch = 4 * dvb + 2 * g16 + (tp >> 1);
-            vlo[dvb] = v0a + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
-            vhi[dvb] = v0a + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
-        }
+        ka0 = k0a + TileSwz<D>::off(r, h);
+        const int ch = 2 * g16 + (tp >> 1);
+        vlo0 = v0a + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
+        vhi0 = v0a + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
     }
     // The phase comes in two parts: WHICH = 0 (addresses of this phase's buffers + the first RD-1 operand requests) runs
     // at the END of the preceding phase, ahead of the barrier, so the LDS latency of the first operands passes while the
     // wave waits for its partner; WHICH = 1 is the MFMA stream.
-    constexpr int RD = 4;   // ring slots: operands are requested RD - 1 MFMAs ahead
+    // RD ring slots: operands are requested RD - 1 MFMAs ahead
     s16x8 ring[RD];
     unsigned kq[NKS], vl[NDV], vh[NDV];
     auto do_M = [&](auto has_pv, auto has_s, auto which, int t) {
@@ -539,9 +539,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
         if constexpr (WHICH == 0) {
             const unsigned vsel = (t % NBUF) * TILE_BYTES, ksel = ((t + (PV ? 1 : 0)) % NBUF) * TILE_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kq[ks] = ka[ks] + ksel;
+            for (int ks = 0; ks < NKS; ++ks) kq[ks] = (ka0 + ksel) ^ (32u * ks);
 #pragma unroll
-            for (int dvb = 0; dvb < NDV; ++dvb) { vl[dvb] = vlo[dvb] + vsel; vh[dvb] = vhi[dvb] + vsel; }
+            for (int dvb = 0; dvb < NDV; ++dvb) { vl[dvb] = (vlo0 + vsel) ^ (64u * dvb); vh[dvb] = (vhi0 + vsel) ^ (64u * dvb); }
         }
         auto fetch = [&](auto jc) {   // operand fragment of step j into its ring slot
             constexpr int j = decltype(jc)::value;
@@ -689,6 +689,11 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
                                    (const uint16_t*)a.v, (uint16_t*)a.o, a.lse, (int)a.n, nqt, c, a.scale, last_arg, (int)(a.nk > 0 ? a.nk : a.n));
                 return hipGetLastError();
             };
+            if constexpr (D == 128 && KB == 4 && !PAD) {   // operand ring depth (option fwd_rd: 4, 6, 8; 0 = default)
+                const int rd = option(OPT_FWD_RD);
+                if (rd == 6) return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD, 6>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD, 6>);
+                if (rd == 8) return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD, 8>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD, 8>);
+            }
             return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD>);
         }
     }
