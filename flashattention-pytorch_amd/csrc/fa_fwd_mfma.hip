@@ -382,7 +382,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     const int qrow = q0 + 32 * w + r;
     const size_t base = (size_t)bh * n * DR, kbase = (size_t)bh * nk * DR;
     const int coff = nk - n;
-    const int stag = w >> 2;   // waves 4..7 (the second wave of every SIMD) run one half-step behind
+    // waves 4..7 (the second wave of every SIMD) run one half-step behind (debug flag 64: waves 0..3 lag instead — does the longer
+    // matrix phase of the lagging half follow the wave's age or its role?)
+    const int stag = ((dr_dbg >> 16) & 64) ? 1 - (w >> 2) : (w >> 2);
 
     const buf_rsrc_t q_rs = make_rsrc(q + base, (unsigned)n * DR * 2);
     s16x8 qf[NKS];
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             // inline asm: hipcc must not see a scalar-memory read in flight, or every LDS wait nearby becomes lgkmcnt(0)
             unsigned long long c;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory");
-            if (lane == 0 && tri < 2040) trace[(w >> 2) * 2048 + tri] = (long long)c;
+            if (lane == 0 && tri < 2040) trace[(w >> 2) * 2048 + tri] = (long long)c;   // (indexed by wave, not by role)
             ++tri;
         }
     };
