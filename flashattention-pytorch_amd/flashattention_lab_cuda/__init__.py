@@ -227,7 +227,8 @@ def _backward(cfn, who, q, k, v, o, do_, lse, causal, softmax_scale, br, bc, ext
             small, fast = small + fp8_slabs, fast + fp8_slabs
         capturing = torch.cuda.is_current_stream_capturing()
         have = 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device))
-        nbytes = plan_backward_workspace(small, fast, have, None if have >= fast else _device_headroom(q.device))
+        # (no device query while a graph is being captured: the buffer then comes from the capture's pool anyway)
+        nbytes = plan_backward_workspace(small, fast, have, None if (have >= fast or capturing) else _device_headroom(q.device))
         ws = _workspace(q.device, nbytes)
         nbytes = max(nbytes, 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device)))
         args = [q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),

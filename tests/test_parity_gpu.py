@@ -940,3 +940,41 @@ def test_workspace_falls_back_to_the_minimum_when_the_device_is_full(device, mon
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     ext.release_workspace()
+
+
+def test_forward_and_backward_inside_a_captured_graph(device):
+    """The calls only enqueue work on the current stream (SURVEY 8b "Threading / streams"), so a step can be captured into a graph
+    and replayed: under capture the shim's workspace is a plain allocation of the capture's own pool (the persistent per-stream
+    buffer is bypassed), nothing synchronises, and the replay reproduces the eager results bit for bit — with new input values
+    too (the graph reads the same tensors)."""
+    import flashattention_lab_cuda as ext
+
+    bh, n, d = 80, 1024, 128                     # 320 row tiles: the dS hand-over (160 MiB of workspace) runs inside the graph
+    q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=61, device=device)
+    scale = d ** -0.5
+
+    def step():
+        o, lse = ext.forward(q, k, v, False, scale, 64, 128)
+        return (o, lse) + tuple(ext.backward(q, k, v, o, do, lse, False, scale, 64, 128))
+
+    eager = [t.clone() for t in step()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                   # warm-up on the capture stream's side, as torch's recipe asks
+    torch.cuda.current_stream().wait_stream(side)
+    before = ext.workspace_stats()["allocations"]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+    assert ext.workspace_stats()["allocations"] == before      # the cache was not touched under capture
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, eager):
+        assert torch.equal(a, b)
+    q.mul_(0.5)                                   # new values in the same tensors
+    graph.replay()
+    torch.cuda.synchronize()
+    eager2 = step()
+    for a, b in zip(outs, eager2):
+        assert torch.equal(a, b)
