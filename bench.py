@@ -117,6 +117,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the separately timed RCCL all-gather and its check")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the gather + its check even with ONE rank: a rehearsal of the "
+                         "multi-GPU code path on a one-GPU box")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing rehearsal without a GPU: gloo, CPU tensors, a placeholder step (no attention is "
                          "computed, value is null); exercises the launcher, the sharding, the barriers and the gather")
@@ -210,13 +213,14 @@ def main(argv=None):
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     sync = (lambda: None) if dry else torch.cuda.synchronize
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import datetime
 
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         tmo = datetime.timedelta(seconds=120)
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
@@ -241,7 +245,7 @@ def main(argv=None):
     chk_lo, chk_hi = shard_bounds(bh_total, world, chk_rank)
     spec = pick_fa2_spec(D)
     scale = D ** -0.5
-    want = [(lo, hi)] + ([(chk_lo, chk_hi)] if rank == 0 and world > 1 and not args.no_gather else [])
+    want = [(lo, hi)] + ([(chk_lo, chk_hi)] if rank == 0 and (world > 1 or args.force_dist) and not args.no_gather else [])
     shards = draw_shards(bh_total, N, D, dtype, dev, args.seed, want)
     q, k, v, do = shards[0]
     q, k, v = (t.requires_grad_(True) for t in (q, k, v))
