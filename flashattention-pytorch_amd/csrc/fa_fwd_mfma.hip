@@ -640,21 +640,41 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     if (tron && lane == 0) trace[(w >> 2) * 2048] = tri;
 
+    // ---- epilogue.  Every wave is past the last barrier and nothing writes LDS any more: the K / V buffers are dead and each
+    // wave takes 32 x D x 2 bytes of them to turn its row-on-the-lane tile into whole-row stores (1 KiB contiguous per store
+    // instruction instead of sixteen 8-byte pieces per lane at a row stride: the per-workgroup store tail is issue bound,
+    // guide T21) — the same staging, and so the same bytes, as the lock-step kernel's epilogue.
     const float l_tot = l_run + wave_half_swap(l_run);
-    if (qrow < n) {
+    if (dbg & 128) {   // A/B: the direct stores of rounds 1 - 2 (8 bytes per lane and instruction)
+        if (qrow < n) {
+            const float inv = 1.f / l_tot;
+            uint16_t* orow = o + base + (size_t)qrow * DR;
+#pragma unroll
+            for (int dvb = 0; dvb < NDV; ++dvb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    u32x2 pk;
+                    pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
+                    pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
+                    if (PAD && 32 * dvb + 8 * gq + 4 * h >= DR) continue;
+                    *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
+                }
+            if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+        }
+        return;
+    }
+    {
         const float inv = 1.f / l_tot;
-        uint16_t* orow = o + base + (size_t)qrow * DR;
+        u32x2 vals[NDV * 4];
 #pragma unroll
         for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                u32x2 pk;
-                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
-                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
-                if (PAD && 32 * dvb + 8 * gq + 4 * h >= DR) continue;   // padded columns (DR is a multiple of 8)
-                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * gq + 4 * h) = pk;
+                vals[4 * dvb + gq][0] = pack2_rn<Tag>(oacc[dvb][4 * gq + 0] * inv, oacc[dvb][4 * gq + 1] * inv);
+                vals[4 * dvb + gq][1] = pack2_rn<Tag>(oacc[dvb][4 * gq + 2] * inv, oacc[dvb][4 * gq + 3] * inv);
             }
-        if (h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
+        store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, o + base, q0 + 32 * w, n, lane, DR);
+        if (qrow < n && h == 0) lse[(size_t)bh * n + qrow] = m_run * scale + logf(l_tot);
     }
 }
 
