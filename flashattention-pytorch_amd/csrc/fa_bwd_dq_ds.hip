@@ -138,23 +138,23 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
     }
     dma_wait_all();   // the stages past the end were requested too (out of range: zeros): nothing may still be writing LDS
 
-    // ---- epilogue: dQ = scale * dQ^T; lane (c, h) holds elements 32 db + 8 g + 4 h .. + 3 of its query row
+    // ---- epilogue: dQ = scale * dQ^T; lane (c, h) holds elements 32 db + 8 g + 4 h .. + 3 of its query row `prow`.  Whole-row
+    // stores through LDS (1 KiB contiguous per instruction instead of sixteen 8-byte pieces per lane: the store tail of a
+    // workgroup is issue bound, guide T21): every DMA of every wave has landed behind the barrier, the stage buffers are dead,
+    // and a wave stages one 32-row block at a time in 8 KiB of its own.
+    __syncthreads();
     const int prow = 16 * (r >> 4) + 8 * ((r & 7) >> 2) + 4 * ((r >> 3) & 1) + (r & 3);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = q0w + 32 * qb + prow;
-        if (qrow < n) {
-            uint16_t* drow = dq + base + (size_t)qrow * D;
+        u32x2 vals[NDB * 4];
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2 val;
-                    val[0] = pack2_rn<Tag>(dqa[qb][db][4 * g + 0] * scale, dqa[qb][db][4 * g + 1] * scale);
-                    val[1] = pack2_rn<Tag>(dqa[qb][db][4 * g + 2] * scale, dqa[qb][db][4 * g + 3] * scale);
-                    *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = val;
-                }
-        }
+            for (int g = 0; g < 4; ++g) {
+                vals[4 * db + g][0] = pack2_rn<Tag>(dqa[qb][db][4 * g + 0] * scale, dqa[qb][db][4 * g + 1] * scale);
+                vals[4 * db + g][1] = pack2_rn<Tag>(dqa[qb][db][4 * g + 2] * scale, dqa[qb][db][4 * g + 3] * scale);
+            }
+        store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, dq + base, q0w + 32 * qb, n, lane, D, prow);
     }
 }
 

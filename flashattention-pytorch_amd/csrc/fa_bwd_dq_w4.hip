@@ -507,21 +507,20 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
     asm volatile("s_nop 15\n\ts_nop 7" : "+a"(dqa[0][0]), "+a"(dqa[0][1]), "+a"(dqa[0][2]), "+a"(dqa[0][3]), "+a"(dqa[1][0]),
                  "+a"(dqa[1][1]), "+a"(dqa[1][2]), "+a"(dqa[1][3]));
     dma_wait_all();   // the tiles past the end were requested too: nothing may still be writing LDS afterwards
+    // whole-row stores through LDS (guide T21): behind the barrier every wave's DMA has landed and the tile buffers are dead;
+    // a wave stages its two 32-row blocks in 16 KiB of its own
+    __syncthreads();
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = q0w + 32 * qb + r;
-        if (qrow < n) {
-            uint16_t* drow = dq + base + (size_t)qrow * D;
+        u32x2 vals[NDB * 4];
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2 val;
-                    val[0] = pack2_rn<Tag>(dqa[qb][db][4 * g + 0] * scale, dqa[qb][db][4 * g + 1] * scale);
-                    val[1] = pack2_rn<Tag>(dqa[qb][db][4 * g + 2] * scale, dqa[qb][db][4 * g + 3] * scale);
-                    *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * h) = val;
-                }
-        }
+            for (int g = 0; g < 4; ++g) {
+                vals[4 * db + g][0] = pack2_rn<Tag>(dqa[qb][db][4 * g + 0] * scale, dqa[qb][db][4 * g + 1] * scale);
+                vals[4 * db + g][1] = pack2_rn<Tag>(dqa[qb][db][4 * g + 2] * scale, dqa[qb][db][4 * g + 3] * scale);
+            }
+        store_rows_via_lds<D>(smem + (2 * w + qb) * 32 * D * 2, vals, dq + base, q0w + 32 * qb, n, lane, D);
     }
     if (it + 1 < ntile_wg) __syncthreads();   // the tile buffers are about to be refilled
     }   // query tiles of this workgroup

@@ -295,11 +295,13 @@ __device__ __forceinline__ void dma_stage_tile(rsrc_s_t rsrc, char* tile, int ro
 // ---- epilogue: a wave's 32 x D result tile, held "row on the lane" (lane (r, h) owns 4-element pieces at columns
 // 32 b + 8 g + 4 h of row r), goes through a wave-private LDS region and leaves as whole rows: 1 KiB contiguous per
 // store instruction instead of 64 scattered 16-byte pieces (the per-workgroup tail is store-issue bound).
+// `lrow`: the row of the 32-row tile this lane's values belong to (default: lane & 31; the dQ product kernel's lanes hold their
+// rows in the order of the kernel that wrote its operand tiles).
 template <int D>
 __device__ __forceinline__ void store_rows_via_lds(char* wl, const u32x2 (&vals)[(D / 32) * 4], uint16_t* gdst, int row0,
-                                                   int n, int lane, int dr = D) {
+                                                   int n, int lane, int dr = D, int lrow = -1) {
     constexpr int CPR = D / 8, RPI = 512 / D, ROWB = 2 * D;   // chunks per row, rows per 1-KiB store, row bytes
-    const int r = lane & 31, h = lane >> 5;
+    const int r = lrow < 0 ? (lane & 31) : lrow, h = lane >> 5;
 #pragma unroll
     for (int b = 0; b < D / 32; ++b)
 #pragma unroll

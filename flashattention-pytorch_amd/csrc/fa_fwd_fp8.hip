@@ -604,20 +604,21 @@ __global__ __launch_bounds__(512, 2) void fwd_fp8v_kernel(const uint8_t* __restr
         __syncthreads();
     }
 
+    // every wave is past the last barrier (the tile loops end with one): the K / V buffers are dead and each wave turns its
+    // row-on-the-lane tile into whole-row stores through 8 KiB of them (fa_fwd_mfma.hip's epilogue)
     const float l_tot = l_run + wave_half_swap(l_run);
-    if (qrow < n) {
+    {
         const float inv = 1.f / l_tot;
-        uint16_t* orow = o + base + (size_t)qrow * D;
+        u32x2 vals[NDV * 4];
 #pragma unroll
         for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                u32x2 pk;
-                pk[0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
-                pk[1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + 32 * dvb + 8 * g + 4 * h) = pk;
+                vals[4 * dvb + g][0] = pack2_rn<Tag>(oacc[dvb][4 * g + 0] * inv, oacc[dvb][4 * g + 1] * inv);
+                vals[4 * dvb + g][1] = pack2_rn<Tag>(oacc[dvb][4 * g + 2] * inv, oacc[dvb][4 * g + 3] * inv);
             }
-        if (h == 0) lse[(size_t)bh * n + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+        store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, o + base, q0 + 32 * w, n, lane, D);
+        if (qrow < n && h == 0) lse[(size_t)bh * n + qrow] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
 
