@@ -579,10 +579,10 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             for_each_const(fetch, std::make_integer_sequence<int, RD - 1>{});
         } else {
             // the matrix-phase wave outranks its partner's vector phase (option fwd_hs = 1 turns this off for the A/B)
-            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(2);
+            if (!(dbg & (16 | 256))) __builtin_amdgcn_s_setprio(2);
             for_each_const(step, std::make_integer_sequence<int, NSTEP>{});
             mfma_stream_fence(sacc, oacc);   // the vector phase reads sacc / oacc by VALU right after the barrier
-            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+            if (!(dbg & (16 | 256))) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -607,6 +607,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
         __syncthreads();
         stamp();
     };
+    if ((dbg & 256) && stag) __builtin_amdgcn_s_setprio(1);   // A/B: one static priority for the younger half, no per-phase flips (guide, two waves per SIMD, item 4)
     dma_stage_tile<D, BN, 8>(k_rs, Kbuf, 0, dma_voff, w, DR);
     if (NBUF == 3) {
         dma_stage_tile<D, BN, 8>(k_rs, Kbuf + TILE_BYTES, BN, dma_voff, w, DR);
