@@ -107,12 +107,22 @@ __device__ __forceinline__ unsigned bits_of_words(const unsigned (&wd)[4]) {
     for (int g = 0; g < 4; ++g) zero_byte |= (wd[g] - 0x01010101u) & ~wd[g] & 0x80808080u;
     if (__all(zero_byte == 0)) return 0xffffu;
     if (__all((wd[0] | wd[1] | wd[2] | wd[3]) == 0)) return 0u;
+    // bit 4 g + j = byte j of word g is non-zero.  Branch-free on the whole word (round 3; was a shift, mask, compare and select
+    // per byte): bit 7 of every non-zero byte, then the four bits gathered with three shifts — 11 instructions per four
+    // elements instead of 16.
     unsigned bits = 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bits |= ((wd[g] >> (8 * j)) & 0xffu) ? (1u << (4 * g + j)) : 0u;
+    for (int g = 0; g < 4; ++g) {
+        const unsigned nz = (((wd[g] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | wd[g]) & 0x80808080u;
+        bits |= (((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xfu) << (4 * g);
+    }
     return bits;
+}
+// s where bit i of `vis` is set, -inf where it is not: a sign-extended one-bit field as the select mask of a bit-field insert
+// (two instructions, no compare / VCC round trip)
+__device__ __forceinline__ float keep_or_minus_inf(float s, unsigned vis, int i) {
+    const int m = ((int)(vis << (31 - i))) >> 31;                     // v_bfe_i32: 0 or -1
+    return __uint_as_float((__float_as_uint(s) & (unsigned)m) | (0xff800000u & ~(unsigned)m));   // v_bfi_b32
 }
 __device__ __forceinline__ unsigned dense_bits_q(const MaskSrc& m, int row, int nk, int kcol) {
     if (m.dwords) {
@@ -288,8 +298,7 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
                 for (int kb = 0; kb < KB; ++kb)
                     if (__any(vis[kb] != 0xffffu)) {   // wave-uniform
 #pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (!((vis[kb] >> i) & 1u)) sacc[kb][i] = -INFINITY;
+                        for (int i = 0; i < 16; ++i) sacc[kb][i] = keep_or_minus_inf(sacc[kb][i], vis[kb], i);
                     }
             }
             // ---- online softmax (fa_fwd_mfma.hip), with rows that have not met a visible key yet (m = -inf)

@@ -289,3 +289,35 @@ def test_an_empty_side_gives_zero_gradients_and_minus_infinity_lse(dtype, device
     dq, dk, dv = ext.ex_backward(full, empty, empty, o, full, lse, True, 0.2)
     assert not dq.any() and dk.shape == (bh, 0, d) and dv.shape == (bh, 0, d)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape", ["key_padding_b", "key_padding_shared", "per_batch", "per_head_3d"])
+def test_broadcast_masks_through_the_wrapper(shape, device):
+    """masks that are only BROADCASTABLE to (B, H, Nq, Nk) — a key-padding mask (B, 1, 1, Nk) or (1, 1, 1, Nk), a per-batch
+    mask (B, 1, Nq, Nk), a 3-D (H, Nq, Nk) one — give what ordinary broadcasting gives (the reference indexes the mask as 4-D and
+    lets masked_fill broadcast, flashattention_pytorch.py:139-141)."""
+    from common.attention_ex import flash_attention_ex
+
+    b, h, nq, nk, d = 2, 3, 70, 90, 64
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn((b, h, nq, d), generator=g).to(torch.bfloat16)
+    k = torch.randn((b, h, nk, d), generator=g).to(torch.bfloat16)
+    v = torch.randn((b, h, nk, d), generator=g).to(torch.bfloat16)
+    if shape == "key_padding_b":
+        mask = torch.ones((b, 1, 1, nk), dtype=torch.bool)
+        mask[0, ..., 60:] = False
+        mask[1, ..., 33:] = False
+    elif shape == "key_padding_shared":
+        mask = torch.ones((1, 1, 1, nk), dtype=torch.bool)
+        mask[..., 77:] = False
+    elif shape == "per_batch":
+        mask = torch.rand((b, 1, nq, nk), generator=g) > 0.3
+        mask[..., 0] = True
+    else:
+        mask = torch.rand((h, nq, nk), generator=g) > 0.3
+        mask[..., 0] = True
+    full = torch.broadcast_to(mask, (b, h, nq, nk)).reshape(b * h, nq, nk)
+    o = flash_attention_ex(q.to(device), k.to(device), v.to(device), mask=mask.to(device))
+    ro, _ = orc.extended_attention(q.reshape(b * h, nq, d), k.reshape(b * h, nk, d), v.reshape(b * h, nk, d), mask=full)
+    assert o.shape == q.shape
+    torch.testing.assert_close(o.cpu().float().reshape(b * h, nq, d), ro.float(), rtol=5e-2, atol=5e-2)
