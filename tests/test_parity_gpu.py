@@ -978,3 +978,34 @@ def test_forward_and_backward_inside_a_captured_graph(device):
     eager2 = step()
     for a, b in zip(outs, eager2):
         assert torch.equal(a, b)
+
+
+def test_bench_line_explains_itself_on_the_device():
+    """the bench line must be able to explain its own discrepancy.  A small run of bench.py on the device:
+    the driver-contract fields, the per-step event times, the library's kernel sum, the allocator's counters inside the timed
+    region (zero device allocations: the workspace is the shim's persistent buffer, warm-up and timed loops are the same
+    code), and the `inconsistent` flag consistent with its own definition."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "8", "--heads", "32",
+                        "--seqlen", "2048", "--settle-seconds", "0.3", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "step_ms", "kernel_ms_sum", "host_overhead_frac", "inconsistent", "allocator"):
+        assert key in d, key
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["step_ms"]["min"] <= d["step_ms"]["median"] <= d["step_ms"]["max"]
+    assert d["allocator"]["num_device_alloc"] == 0 and d["allocator"]["num_alloc_retries"] == 0 and d["allocator"]["num_ooms"] == 0
+    assert d["inconsistent"] == (d["ms_per_step"] > 1.1 * d["kernel_ms_sum"])
+    assert d["inconsistent"] is False, (d["ms_per_step"], d["kernel_ms_sum"])      # 256 units x 2048: the GPU is the bottleneck
+    roof = d["roofline"]
+    assert roof["traffic"] is None and roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["peak"] == 2500.0
+    assert abs(sum(k["ms_per_step"] for k in roof["kernels"].values()) - d["kernel_ms_sum"]) < 1e-2
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
