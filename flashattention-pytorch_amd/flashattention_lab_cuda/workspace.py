@@ -2,11 +2,12 @@
 
 The reference's backward allocates its scratch on every call (`/root/reference/csrc/fa2/fa2_bwd.cu:53-57`: three fp32
 tensors through ATen's allocator).  Here the scratch is the C library's caller-owned workspace (include/fa_mi355x.h), and a
-per-call `torch.empty` of it has two costs the kernels never see: the caching allocator may split a cached block for another
-tensor and then has to `hipMalloc` the workspace again inside a training step (≈ 30 ms per GB), and a transient multi-GB
-request is what fragments a tight pool.  So the shim keeps ONE buffer per (device, stream), sized by the largest request so
-far, handed to every call on that stream (calls on one stream are ordered, so they can share it; calls on different streams
-get different buffers), and released only by `release()`.
+per-call `torch.empty` of it puts the caching allocator into every backward: it may split a cached block for another tensor and
+send the workspace request to the device allocator inside a training step, a failed multi-GB request makes torch synchronise the
+device and empty its cache before the retry, and a transient multi-GB block is what fragments a tight pool (DESIGN.md section 0:
+round 2's driver-timed step spent 11.85 of its 19.28 ms on the host side of exactly this path).  So the shim keeps ONE buffer per
+(device, stream), sized by the largest request so far, handed to every call on that stream (calls on one stream are ordered, so
+they can share it; calls on different streams get different buffers), and released only by `release()`.
 
 While a stream is being captured into a graph the cache is bypassed: the buffer then has to belong to the graph's own pool.
 
