@@ -40,8 +40,8 @@ hipEvent_t prof_get_event() {
 }
 
 // ---- tuning knobs ---------------------------------------------------------------------------------
-constexpr const char* kOptNames[fa::OPT_COUNT] = {"fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "dkdv_abl", "dq", "dq_abl", "ex_path", "ds_chunk_mb", "fp8_pv", "fwd_rd"};
-constexpr const char* kOptEnv[fa::OPT_COUNT] = {"FA_FWD_KB", "FA_FWD_STAG", "FA_DKDV", "FA_DQ_KT", "FA_FWD_RS", "FA_DKDV_KREG", "FA_FWD_EAGER", "FA_FWD_HS", "FA_FWD_TPW", "FA_DQ_TPW", "FA_DKDV_TPW", "FA_DQ_NLF", "FA_DQ_W4", "FA_FWD_ABL", "FA_SMALL_GRID", "FA_FP8_ROT", "FA_DKDV_STG", "FA_DKDV_ABL", "FA_DQ", "FA_DQ_ABL", "FA_EX_PATH", "FA_DS_CHUNK_MB", "FA_FP8_PV", "FA_FWD_RD"};
+constexpr const char* kOptNames[fa::OPT_COUNT] = {"fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "dkdv_abl", "dq", "dq_abl", "ex_path", "ds_chunk_mb", "fp8_pv", "fwd_rd", "fwd_w2"};
+constexpr const char* kOptEnv[fa::OPT_COUNT] = {"FA_FWD_KB", "FA_FWD_STAG", "FA_DKDV", "FA_DQ_KT", "FA_FWD_RS", "FA_DKDV_KREG", "FA_FWD_EAGER", "FA_FWD_HS", "FA_FWD_TPW", "FA_DQ_TPW", "FA_DKDV_TPW", "FA_DQ_NLF", "FA_DQ_W4", "FA_FWD_ABL", "FA_SMALL_GRID", "FA_FP8_ROT", "FA_DKDV_STG", "FA_DKDV_ABL", "FA_DQ", "FA_DQ_ABL", "FA_EX_PATH", "FA_DS_CHUNK_MB", "FA_FP8_PV", "FA_FWD_RD", "FA_FWD_W2"};
 // a name added to OptionId without its two strings here would leave a null at the end of a table
 template <size_t N> constexpr bool all_set(const char* const (&t)[N]) {
     for (size_t i = 0; i < N; ++i)

@@ -193,6 +193,21 @@ template <int N> __device__ __forceinline__ void lds_wait_for(s16x8& x) {
     };
 FA_MFMA_WAIT_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
 FA_MFMA_WAIT_IMPL(f16, "v_mfma_f32_32x32x16_f16")
+// the same MFMAs without a wait (their operand's arrival is covered by an earlier counted wait)
+#define FA_MFMA_NOWAIT_IMPL(TAG, OPC)                                                                                   \
+    struct MfmaNoWait_##TAG {                                                                                           \
+        static __device__ __forceinline__ void acc(s16x8 a, s16x8 b, f32x16& c) {                                       \
+            asm volatile(OPC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));                                             \
+        }                                                                                                               \
+        static __device__ __forceinline__ void first(s16x8 a, s16x8 b, f32x16& c) {                                     \
+            asm volatile(OPC " %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));                                              \
+        }                                                                                                               \
+    };
+FA_MFMA_NOWAIT_IMPL(bf16, "v_mfma_f32_32x32x16_bf16")
+FA_MFMA_NOWAIT_IMPL(f16, "v_mfma_f32_32x32x16_f16")
+template <typename Tag> struct MfmaNoWait;
+template <> struct MfmaNoWait<bf16_tag> : MfmaNoWait_bf16 {};
+template <> struct MfmaNoWait<f16_tag> : MfmaNoWait_f16 {};
 template <typename Tag, int N> struct MfmaWait;
 template <int N> struct MfmaWait<bf16_tag, N> : MfmaWait_bf16<N> {};
 template <int N> struct MfmaWait<f16_tag, N> : MfmaWait_f16<N> {};

@@ -355,7 +355,9 @@ hipError_t set_trace_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tra
 // lgkmcnt waits fused to each MFMA, P.V and S accumulation chains interleaved.  K and V are triple buffered with the
 // LDS-DMA issued two tiles ahead at even global half-steps g = 2u (K(u+2), V(u+1)) and counted vmcnt waits, so a
 // transfer has four half-steps to land.
-template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false, int RD = 4>
+// W2: one counted operand wait per TWO MFMAs (an even step also waits for the next step's operand, an odd step issues none), as
+// the backward stream kernels do: one instruction less per two steps on an issue port that is 80 % busy (option fwd_w2).
+template <typename Tag, int D, bool CAUSAL, int KB, bool PAD = false, int RD = 4, bool W2 = false>
 __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                                float* __restrict__ lse, int n, int nqt, float c_log2,
@@ -563,14 +565,24 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_stag_kernel(const uint16_t* _
             constexpr int j = decltype(jc)::value, x = Map::idx(j);
             fetch(std::integral_constant<int, j + RD - 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int newer = [&]() constexpr { int c = 0; for (int q = 1; q < RD; ++q) c += nops(j + q); return c; }();
+            // LDS instructions issued after the operand this step waits for: its own, or (W2, even steps) the next step's;
+            // W2's odd steps issue no wait: the even step before them has covered their operand
+            constexpr bool waits = !W2 || (j % 2) == 0;
+            constexpr int nw = [&]() constexpr { int c = 0; for (int q = (W2 ? 2 : 1); q < RD; ++q) c += nops(j + q); return c; }();
+            static_assert(!W2 || NSTEP % 2 == 0, "W2 pairs the steps");
             if constexpr (Map::is_pv(j)) {
                 constexpr int kb = x / (2 * NDV), s2 = (x / NDV) & 1, dvb = x % NDV;
-                MfmaWait<Tag, newer>::acc(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
+                if constexpr (waits) MfmaWait<Tag, nw>::acc(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
+                else MfmaNoWait<Tag>::acc(ring[j % RD], *reinterpret_cast<s16x8*>(&pp[kb][s2]), oacc[dvb]);
             } else {
                 constexpr int kb = x % KB, ks = x / KB;
-                if constexpr (ks == 0) MfmaWait<Tag, newer>::first(ring[j % RD], qf[ks], sacc[kb]);
-                else MfmaWait<Tag, newer>::acc(ring[j % RD], qf[ks], sacc[kb]);
+                if constexpr (ks == 0) {
+                    if constexpr (waits) MfmaWait<Tag, nw>::first(ring[j % RD], qf[ks], sacc[kb]);
+                    else MfmaNoWait<Tag>::first(ring[j % RD], qf[ks], sacc[kb]);
+                } else {
+                    if constexpr (waits) MfmaWait<Tag, nw>::acc(ring[j % RD], qf[ks], sacc[kb]);
+                    else MfmaNoWait<Tag>::acc(ring[j % RD], qf[ks], sacc[kb]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -714,6 +726,7 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t st, bool want_stag 
             };
             if constexpr (D == 128 && KB == 4 && !PAD) {   // operand ring depth (option fwd_rd: 4, 6, 8; 0 = default)
                 const int rd = option(OPT_FWD_RD);
+                if (option(OPT_FWD_W2) == 1) return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD, 6, true>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD, 6, true>);
                 if (rd == 6) return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD, 6>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD, 6>);
                 if (rd == 8) return a.causal ? launch_s(fwd_mfma_stag_kernel<Tag, D, true, KB, PAD, 8>) : launch_s(fwd_mfma_stag_kernel<Tag, D, false, KB, PAD, 8>);
             }

@@ -50,7 +50,7 @@ hipError_t ensure_dynamic_smem(const void* kernel, int bytes);
 // Tuning knobs (tile sweep / A-B runs).  Each starts from an environment variable of the same upper-case name with
 // an FA_ prefix (FA_FWD_KB, FA_FWD_STAG, FA_DKDV (4|8), FA_DQ_KT, FA_FWD_RS, FA_DKDV_KREG, FA_FWD_EAGER, FA_FWD_HS, FA_FWD_TPW, FA_DQ_TPW, FA_DKDV_TPW, FA_DQ_NLF, FA_DQ_W4, FA_FWD_ABL, FA_SMALL_GRID, FA_FP8_ROT, FA_DKDV_STG) and can be changed at run time through
 // fa_set_option() so that variants can be interleaved in one process.
-enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_DS_CHUNK_MB, OPT_FP8_PV, OPT_FWD_RD, OPT_COUNT };
+enum OptionId { OPT_FWD_KB = 0, OPT_FWD_STAG, OPT_DKDV, OPT_DQ_KT, OPT_FWD_RS, OPT_DKDV_KREG, OPT_FWD_EAGER, OPT_FWD_HS, OPT_FWD_TPW, OPT_DQ_TPW, OPT_DKDV_TPW, OPT_DQ_NLF, OPT_DQ_W4, OPT_FWD_ABL, OPT_SMALL_GRID, OPT_FP8_ROT, OPT_DKDV_STG, OPT_DKDV_ABL, OPT_DQ, OPT_DQ_ABL, OPT_EX_PATH, OPT_DS_CHUNK_MB, OPT_FP8_PV, OPT_FWD_RD, OPT_FWD_W2, OPT_COUNT };
 int option(int id);
 int set_option(const char* name, int value);   // returns 0, or -1 for an unknown name
 
