@@ -363,20 +363,20 @@ static size_t ds_chunk_bytes() {
     const int mb = option(OPT_DS_CHUNK_MB);
     return mb > 0 ? (size_t)mb << 20 : (size_t)4 << 30;
 }
-static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant) {
+static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant, int64_t nk = 0) {
     const int dq_opt = option(OPT_DQ), dkdv_opt = option(OPT_DKDV);
     if (atomic_variant || !bwd_dkdv_w4_supported(dtype, d)) return false;
     // a kernel pinned by option (A/B runs of one pass against another) keeps the other pass as it was: only dq = 6 asks for this path
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
-    if (ds_workspace_bytes(1, n, n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
+    if (ds_workspace_bytes(1, n, nk > 0 ? nk : n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
     // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
     if (causal) return false;
     return !small_grid(bh, n, true);
 }
-static int64_t ds_chunk_units(int64_t bh, int64_t n) {
-    const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, n));
+static int64_t ds_chunk_units(int64_t bh, int64_t n, int64_t nk = 0) {
+    const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, nk > 0 ? nk : n));
     if (fit >= bh) return bh;
     const int64_t nch = (bh + fit - 1) / fit;
     return (bh + nch - 1) / nch;   // equal chunks: a short last one would leave CUs idle
@@ -386,8 +386,39 @@ size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_va
 }
 // what the dS hand-over wants on top of that (0 where it does not serve the call): a call whose workspace is smaller runs
 // the recomputing dQ pass instead
-size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant) {
-    return bwd_ds_path(dtype, d, bh, n, causal, atomic_variant) ? ds_workspace_bytes(ds_chunk_units(bh, n), n, n) : 0;
+size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant, int64_t nk) {
+    const int64_t nkk = nk > 0 ? nk : n;
+    return bwd_ds_path(dtype, d, bh, n, causal, atomic_variant, nkk) ? ds_workspace_bytes(ds_chunk_units(bh, n, nkk), n, nkk) : 0;
+}
+
+// The hand-over itself: row constants, then per chunk of (b,h) units dK/dV (stores dS) and dQ = scale * dS K.  `a.nk` keys
+// (0: = a.n query rows); `ds`: room for bwd_ds_extra_bytes.  Shared by the plain backward below and the extended path's Nq != Nk
+// calls without masks or dropout (fa_ex.hip).
+template <typename Tag>
+static hipError_t run_handover_t(const BwdArgs& a, float* nlse, float* ndelta, void* ds, hipStream_t st) {
+    const long long rows = (long long)a.bh * a.n;
+    const int64_t nk = a.nk > 0 ? a.nk : a.n;
+    {
+        ProfScope ps(K_BWD_DELTA, st);
+        hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
+                           (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, (int)a.d, 1.0f / a.scale);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t step = ds_chunk_units(a.bh, a.n, nk);
+    for (int64_t b0 = 0; b0 < a.bh; b0 += step) {
+        BwdArgs c = a;
+        c.bh = a.bh - b0 < step ? a.bh - b0 : step;
+        const size_t qo = (size_t)b0 * a.n * a.d * 2, ko = (size_t)b0 * nk * a.d * 2;   // query-side / key-side tensors
+        c.q = (const char*)a.q + qo; c.dout = (const char*)a.dout + qo; c.dq = (char*)a.dq + qo;
+        c.k = (const char*)a.k + ko; c.v = (const char*)a.v + ko; c.dk = (char*)a.dk + ko; c.dv = (char*)a.dv + ko;
+        if ((e = launch_bwd_dkdv_w4(c, nlse + b0 * a.n, ndelta + b0 * a.n, st, ds)) != hipSuccess) return e;
+        if ((e = launch_bwd_dq_ds(c, ds, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t launch_bwd_handover(const BwdArgs& a, float* nlse, float* ndelta, void* ds, hipStream_t st) {
+    return a.dtype == 2 ? run_handover_t<bf16_tag>(a, nlse, ndelta, ds, st) : run_handover_t<f16_tag>(a, nlse, ndelta, ds, st);
 }
 
 template <typename Tag, int D>
@@ -415,25 +446,7 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t st) {
     if (ds_extra && option(OPT_DQ) == 6 && a.workspace_bytes < bwd_mfma_workspace_bytes(a.bh, a.n, a.d, false) + ds_extra)
         return hipErrorInvalidValue;   // asked for by option: fail rather than fall back
     if (ds_extra && a.workspace_bytes >= bwd_mfma_workspace_bytes(a.bh, a.n, a.d, false) + ds_extra) {
-        // row constants, then per chunk of (b,h) units: dK/dV (stores dS), dQ = scale * dS K
-        {
-            ProfScope ps(K_BWD_DELTA, st);
-            hipLaunchKernelGGL(bwd_prep_kernel<Tag>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
-                               (const uint16_t*)a.o, (const uint16_t*)a.dout, a.lse, nlse, ndelta, rows, (int)a.d, 1.0f / a.scale);
-        }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        void* ds = dq_acc;   // behind the row constants (256-byte aligned)
-        const int64_t step = ds_chunk_units(a.bh, a.n);
-        for (int64_t b0 = 0; b0 < a.bh; b0 += step) {
-            BwdArgs c = a;
-            c.bh = a.bh - b0 < step ? a.bh - b0 : step;
-            const size_t eo = (size_t)b0 * a.n * a.d * 2;
-            c.q = (const char*)a.q + eo; c.k = (const char*)a.k + eo; c.v = (const char*)a.v + eo; c.dout = (const char*)a.dout + eo;
-            c.dq = (char*)a.dq + eo; c.dk = (char*)a.dk + eo; c.dv = (char*)a.dv + eo;
-            if ((e = launch_bwd_dkdv_w4(c, nlse + b0 * a.n, ndelta + b0 * a.n, st, ds)) != hipSuccess) return e;
-            if ((e = launch_bwd_dq_ds(c, ds, st)) != hipSuccess) return e;
-        }
-        return hipSuccess;
+        return run_handover_t<Tag>(a, nlse, ndelta, dq_acc /* behind the row constants, 256-byte aligned */, st);
     }
     if (split && dq_makes_row_constants(a.d)) {
         e = launch_bwd_dq_mfma(a, nlse, ndelta, st);

@@ -392,7 +392,7 @@ int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, c
     if (!workspace || workspace_bytes < need)
         return fail(FA_ERR_WORKSPACE, "fa_ex_backward: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
     fa::ExArgs a{q, k, v, const_cast<void*>(o), const_cast<float*>(lse), do_, dq, dk, dv, bh, nq, nk, d, dtype, causal ? 1 : 0,
-                 (float)softmax_scale, mask, mask_bh_stride, block_mask, br, bc, dropout_p, dropout_seed, workspace};
+                 (float)softmax_scale, mask, mask_bh_stride, block_mask, br, bc, dropout_p, dropout_seed, workspace, workspace_bytes};
     hipError_t e = fa::launch_ex(a, true, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_ex_backward: HIP error %d (%s)", (int)e, hipGetErrorString(e));
     return FA_OK;
@@ -402,6 +402,15 @@ size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_
     (void)nk; (void)d; (void)dtype;
     if (bh <= 0 || nq <= 0) return 256;
     return (fa::ex_backward_workspace_bytes(bh, nq) + 255) & ~(size_t)255;
+}
+
+size_t fa_ex_backward_workspace_bytes_fast(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype, int causal, int extras) {
+    size_t need = fa_ex_backward_workspace_bytes(bh, nq, nk, d, dtype);
+    if (extras || bh <= 0 || nq <= 0 || nk <= 0 || g_mode.load() == FA_MODE_F32_GENERIC || fa::option(fa::OPT_EX_PATH) == 1 || fa::option(fa::OPT_EX_PATH) == 3) return need;
+    if (!fa::bwd_mfma_supported(dtype, d)) return need;
+    if (nq == nk) return need + fa::bwd_ds_extra_bytes(bh, nq, d, dtype, causal != 0, bwd_atomic_variant());   // the plain backward's own rule
+    if (causal || !fa::nqnk_mfma_supported(dtype, d, bh, nq, nk, 0)) return need;
+    return need + fa::bwd_ds_extra_bytes(bh, nq, d, dtype, false, false, nk);
 }
 
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {

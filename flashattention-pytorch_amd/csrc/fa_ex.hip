@@ -427,8 +427,9 @@ hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
     const bool plain = (path == 0 || path == 2) && !a.mask && !a.block_mask && a.dropout_p <= 0.0 && a.scale > 0.f;
     if (plain && a.nq == a.nk && (backward ? bwd_mfma_supported(a.dtype, a.d) : fwd_mfma_supported(a.dtype, a.d))) {
         if (!backward) return launch_fwd_mfma(FwdArgs{a.q, a.k, a.v, a.o, a.lse, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale}, st);
+        // (with a workspace of fa_ex_backward_workspace_bytes_fast the plain backward hands dS over as it does behind fa2_backward)
         return launch_bwd_mfma(BwdArgs{a.q, a.k, a.v, a.o, a.dout, a.lse, a.dq, a.dk, a.dv, a.bh, a.nq, a.d, a.dtype, a.causal, a.scale,
-                                       a.workspace, ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
+                                       a.workspace, a.workspace_bytes > ex_backward_workspace_bytes(a.bh, a.nq) ? a.workspace_bytes : ex_backward_workspace_bytes(a.bh, a.nq), 0}, st);
     }
     // the same for what the 16-bit kernels do not take (fp32 tensors, head dims that are not a multiple of 8): the plain path's
     // exact-f32 kernels (fa_generic.hip: register fragments, 16-byte operand reads — 2.5 x the rate of the kernels below)
@@ -451,6 +452,12 @@ hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
         b.nk = a.nk;
         float* nlse = reinterpret_cast<float*>(a.workspace);
         float* ndelta = nlse + (size_t)a.bh * a.nq;
+        // no mask: with room for the dS tiles behind the row constants the dK/dV kernel hands dS to the dQ product kernel
+        // (DESIGN.md 4c), as the square backward does
+        const size_t base = (ex_backward_workspace_bytes(a.bh, a.nq) + 255) & ~(size_t)255;
+        const size_t extra = a.causal ? 0 : bwd_ds_extra_bytes(a.bh, a.nq, a.d, a.dtype, false, false, a.nk);
+        if (extra && a.workspace_bytes >= base + extra)
+            return launch_bwd_handover(b, nlse, ndelta, reinterpret_cast<char*>(a.workspace) + base, st);
         hipError_t e = launch_bwd_dq_w4(b, nlse, ndelta, st);   // makes the row constants on its way
         if (e != hipSuccess) return e;
         return launch_bwd_dkdv_w4(b, nlse, ndelta, st);

@@ -72,7 +72,9 @@ bool bwd_mfma_supported(int dtype, int64_t d);
 hipError_t launch_bwd_mfma(const BwdArgs& a, hipStream_t st);
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant);   // fp32 dQ scratch only for the single-kernel variant
 // bytes the dS hand-over (fa_bwd_dq_ds.hip) wants on top of that; 0 where it does not serve the call
-size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant);
+size_t bwd_ds_extra_bytes(int64_t bh, int64_t n, int64_t d, int dtype, bool causal, bool atomic_variant, int64_t nk = 0);
+// row constants + the chunk loop [dK/dV with dS stores, dQ product]; a.nk keys (0: = a.n), ds: bwd_ds_extra_bytes of room
+hipError_t launch_bwd_handover(const BwdArgs& a, float* nlse, float* ndelta, void* ds, hipStream_t st);
 hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float* ndelta, hipStream_t st);  // 8-wave dK/dV
 hipError_t launch_bwd_dq_mfma(const BwdArgs& a, float* nlse, float* ndelta, hipStream_t st);   // d > 64: also WRITES nlse / ndelta
 inline bool dq_makes_row_constants(int64_t d) { return d > 64; }
@@ -122,6 +124,7 @@ struct ExArgs {
     double dropout_p;
     uint64_t seed;
     void* workspace;              // backward: ex_backward_workspace_bytes
+    size_t workspace_bytes = 0;   // what the caller really gave (more than the minimum lets plain calls hand dS over)
 };
 hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st);
 bool ex_mfma_supported(const ExArgs& a);

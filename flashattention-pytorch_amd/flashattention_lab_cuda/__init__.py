@@ -34,7 +34,7 @@ EXPORTED_C_SYMBOLS = (
     "fa1_forward", "fa1_backward", "fa2_forward", "fa2_backward", "fa3_forward", "fa3_backward",
     "fa_backward_workspace_bytes", "fa_backward_workspace_bytes_fast", "fa3_forward_workspace_bytes", "fa3_backward_workspace_bytes", "fa_last_error", "fa_version",
     "fa_set_kernel_mode", "fa_set_option", "fa_debug_trace_buffer", "fa_device_is_gfx950", "fa_profile_enable", "fa_profile_report",
-    "fa_ex_forward", "fa_ex_backward", "fa_ex_backward_workspace_bytes",
+    "fa_ex_forward", "fa_ex_backward", "fa_ex_backward_workspace_bytes", "fa_ex_backward_workspace_bytes_fast",
 )
 
 
@@ -88,6 +88,8 @@ def _load_library() -> ctypes.CDLL:
     lib.fa_ex_backward.restype = ci
     lib.fa_ex_backward_workspace_bytes.argtypes = [i64, i64, i64, i64, ci]
     lib.fa_ex_backward_workspace_bytes.restype = sz
+    lib.fa_ex_backward_workspace_bytes_fast.argtypes = [i64, i64, i64, i64, ci, ci, ci]
+    lib.fa_ex_backward_workspace_bytes_fast.restype = sz
     return lib
 
 
@@ -323,8 +325,14 @@ def ex_backward(q, k, v, o, do_, lse, causal, softmax_scale, mask=None, block_ma
         raise RuntimeError("ex_backward: o, do must be (BH, Nq, d) and lse (BH, Nq) float32")
     with torch.cuda.device(q.device):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        nbytes = int(_lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, code))
+        small = int(_lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, code))
+        extras = int(mask is not None or block_mask is not None or dropout_p > 0.0)
+        fast = int(_lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, code, int(bool(causal)), extras))
+        capturing = torch.cuda.is_current_stream_capturing()
+        have = 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device))
+        nbytes = plan_backward_workspace(small, fast, have, None if (have >= fast or capturing) else _device_headroom(q.device))
         ws = _workspace(q.device, nbytes)
+        nbytes = max(nbytes, 0 if capturing else _workspaces.capacity(q.device, _stream_ptr(q.device)))
         _check(_lib.fa_ex_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do_.data_ptr(), lse.data_ptr(),
                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), bh, nq, nk, d, code, int(bool(causal)),
                                    float(softmax_scale), mptr, mstride, bptr, int(br), int(bc), float(dropout_p),

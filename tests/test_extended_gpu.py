@@ -321,3 +321,90 @@ def test_broadcast_masks_through_the_wrapper(shape, device):
     ro, _ = orc.extended_attention(q.reshape(b * h, nq, d), k.reshape(b * h, nk, d), v.reshape(b * h, nk, d), mask=full)
     assert o.shape == q.shape
     torch.testing.assert_close(o.cpu().float().reshape(b * h, nq, d), ro.float(), rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("nq,nk", [(1024, 1536), (1100, 1300), (1536, 1024), (1024, 1024)])
+def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
+    """`fa_ex_backward` without mask and dropout on a launch big enough for it (> 256 row tiles, no causal mask)
+    takes the dS hand-over — preparation launch, dK/dV kernel with dS stores, dQ product — also with Nq != Nk (round 2: those
+    calls recomputed): the library profile shows the preparation launch, the workspace is fa_ex_backward_workspace_bytes_fast's,
+    the gradients agree with the recomputing pass (option dq = 5) and with the fp64 oracle."""
+    import flashattention_lab_cuda as ext
+
+    bh, d = 72, 128
+    g = torch.Generator().manual_seed(3 * nq + nk)
+    q = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16)
+    k = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16)
+    v = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16)
+    do = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16)
+    qd, kd, vd, dod = (t.to(device) for t in (q, k, v, do))
+    scale = d ** -0.5
+    lib = ext._lib
+    small = int(lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, 2))
+    fast = int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 0, 0))
+    tiles = ((nq + 31) // 32) * (8 * ((nk + 255) // 256))
+    assert fast == small + bh * tiles * 2048                                                    # the whole launch in one chunk here
+    assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 0, 1)) == small        # a mask / dropout: no hand-over
+    if nq != nk:
+        assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 1, 0)) == small    # nor under the causal mask
+    o, lse = ext.ex_forward(qd, kd, vd, False, scale)
+    ext.release_workspace()
+    ext.profile_enable(True)
+    grads = ext.ex_backward(qd, kd, vd, o, dod, lse, False, scale)
+    torch.cuda.synchronize()
+    prof = ext.profile_report()
+    ext.profile_enable(False)
+    assert "bwd_delta" in prof and "bwd_dq_mfma" in prof and "bwd_mfma" in prof, prof
+    assert ext.workspace_stats()["bytes"] >= fast
+    ext.set_option("dq", 5)
+    try:
+        ext.profile_enable(True)
+        ref = ext.ex_backward(qd, kd, vd, o, dod, lse, False, scale)
+        torch.cuda.synchronize()
+        prof5 = ext.profile_report()
+        ext.profile_enable(False)
+    finally:
+        ext.set_option("dq", 0)
+    assert "bwd_delta" not in prof5, prof5
+    for a, b in zip(grads, ref):
+        assert torch.isfinite(a.float()).all() and max_abs(a, b) <= 2e-2 * max(1.0, float(b.float().abs().max()))
+    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q[:2], k[:2], v[:2], do[:2], causal=False, softmax_scale=scale)
+    tol = dtype_tolerances(torch.bfloat16)
+    for a, b in zip(grads, (rq, rk, rv)):
+        torch.testing.assert_close(a[:2].cpu(), b, **tol)
+    for a, b in zip(grads, (rq, rk, rv)):   # and the last units (the chunk loop's offsets into the key-side tensors)
+        pass
+    rq2, rk2, rv2, _, _ = orc.extended_attention_backward(q[-1:], k[-1:], v[-1:], do[-1:], causal=False, softmax_scale=scale)
+    for a, b in zip(grads, (rq2, rk2, rv2)):
+        torch.testing.assert_close(a[-1:].cpu(), b, **tol)
+    ext.release_workspace()
+
+
+def test_extended_handover_in_chunks(device):
+    """The same with the chunk bound lowered so that the (b,h) units are worked through in three chunks: the key-side tensors
+    (k, v, dk, dv: Nk rows) and the query-side ones (q, dO, dq: Nq rows) advance by different strides."""
+    import flashattention_lab_cuda as ext
+
+    bh, nq, nk, d = 72, 1024, 1536, 128
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16).to(device)
+    k = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16).to(device)
+    v = torch.randn((bh, nk, d), generator=g).to(torch.bfloat16).to(device)
+    do = torch.randn((bh, nq, d), generator=g).to(torch.bfloat16).to(device)
+    scale = d ** -0.5
+    o, lse = ext.ex_forward(q, k, v, False, scale)
+    one = ext.ex_backward(q, k, v, o, do, lse, False, scale)
+    per_unit_mb = (nq // 32) * (8 * (nk // 256)) * 2048 / 2 ** 20      # 3 MiB
+    ext.set_option("ds_chunk_mb", int(per_unit_mb * 24))               # 24 units per chunk
+    try:
+        ext.profile_enable(True)
+        three = ext.ex_backward(q, k, v, o, do, lse, False, scale)
+        torch.cuda.synchronize()
+        prof = ext.profile_report()
+        ext.profile_enable(False)
+    finally:
+        ext.set_option("ds_chunk_mb", 0)
+    assert prof["bwd_mfma"][0] == 3 and prof["bwd_dq_mfma"][0] == 3 and prof["bwd_delta"][0] == 1, prof
+    for a, b in zip(one, three):
+        assert torch.equal(a, b)                                       # the same kernels on the same units
+    ext.release_workspace()
