@@ -53,3 +53,31 @@ def test_random_shape_matches_oracle(bh, n, d, causal, dtype, seed, device):
         assert torch.isfinite(g.float()).all(), name
         torch.testing.assert_close(g, want, **tol, msg=lambda m: f"{name}: {m}")
     torch.testing.assert_close(lse[sel].cpu(), rlse, rtol=1e-3, atol=1e-3)
+
+
+def _fp8_cases(count, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        n = rng.choice([rng.randint(257, 700), rng.randint(701, 2200), rng.choice([320, 384, 448, 512, 1024, 1088])])
+        out.append((rng.randint(1, 3), n, rng.random() < 0.5, rng.choice([torch.bfloat16, torch.float16]), rng.randint(0, 10 ** 6)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bh,n,causal,dtype,seed", _fp8_cases(12, 20261005))
+def test_fuzz_fp8_all_e4m3_forward(bh, n, causal, dtype, seed, device):
+    """Random N around the all-e4m3 kernel's seams (128-key tiles of two 64-key quantisation blocks, odd block counts, the first
+    causal query tile on the 16-bit P.V kernel): finite, within the fp8 bar of the exact result, lse tight against the e4m3 model."""
+    import flashattention_lab_cuda as ext
+
+    d = 128
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.randn((bh, n, d), generator=g).to(dtype) for _ in range(3))
+    o, lse = ext.fa3_forward(q.to(device), k.to(device), v.to(device), causal, d ** -0.5, 64, 128, 2, True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    ro, rlse = orc.exact_attention(q.double(), k.double(), v.double(), causal, d ** -0.5)
+    err = (o.cpu().double() - ro).abs()
+    assert (err <= 1e-1 + 1e-1 * ro.abs().amax(dim=-1, keepdim=True)).all(), float(err.max())
+    _, mlse = orc.fp8_attention(q, k, v, causal, d ** -0.5, 64, 64, p_e4m3=True)
+    assert (lse.cpu() - mlse).abs().max().item() < 2e-2
