@@ -43,6 +43,15 @@ namespace fa {
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:8192\n\t" WAIT("%8") OPC " %3, %6, %7, %3" \
                          : "=&v"(r0), "=&v"(r1), "=&v"(r2), "+a"(c) : "v"(qa), "v"(ka), "v"(a), "v"(b), "n"(N));          \
         }                                                                                                               \
+        /* KR: K rows of key block 0 stay in registers, a group of the S' chains requests Q rows + K rows of block 1 only */ \
+        template <int N> static __device__ __forceinline__ void f2_v(unsigned qa, unsigned ka, s16x8& r0, s16x8& r2, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4 offset:8192\n\t" WAIT("%7") OPC " %2, %5, %6, %2" \
+                         : "=&v"(r0), "=&v"(r2), "+v"(c) : "v"(qa), "v"(ka), "v"(a), "v"(b), "n"(N));                     \
+        }                                                                                                               \
+        template <int N> static __device__ __forceinline__ void f2_a(unsigned qa, unsigned ka, s16x8& r0, s16x8& r2, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4 offset:8192\n\t" WAIT("%7") OPC " %2, %5, %6, %2" \
+                         : "=&v"(r0), "=&v"(r2), "+a"(c) : "v"(qa), "v"(ka), "v"(a), "v"(b), "n"(N));                     \
+        }                                                                                                               \
         template <int N, int OFF> static __device__ __forceinline__ void fb_v(unsigned qa, s16x8& r0, s16x8 a, s16x8 b, f32x16& c) { \
             asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" WAIT("%6") OPC " %1, %3, %4, %1"             \
                          : "=&v"(r0), "+v"(c) : "v"(qa), "v"(a), "v"(b), "n"(OFF), "n"(N));                             \
@@ -207,7 +216,10 @@ constexpr Op kSched[64][kWidth] = {
 // workgroup 16 KiB.  Element j of lane (r, h) is query 16 s + 8 (j >> 2) + 4 h + (j & 3) of the block (the accumulator's
 // register order); fa_bwd_dq_ds.hip reads the tiles back transposed (ds_read_b64_tr_b16).  Blocks the causal mask removes
 // whole (queries before the wave's first key) are never written; masked elements of the others are written as 0.
-template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1), bool DS = false>
+// KR (round 3): the K rows of the wave's FIRST key block stay in 32 registers (the non-causal kernels have 46 spare), so a group of
+// the S' chains requests two fragments instead of three: 40 LDS operand reads per block instead of 48 (0.625 KB per MFMA instead
+// of 0.75), a 10-slot operand ring instead of 16.
+template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1), bool DS = false, bool KR = false>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                                                              uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
                                                              float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */,
                                                              uint16_t* __restrict__ ds = nullptr, int nqb = 0, int nkb32 = 0 /* DS: tile grid of the dS workspace */) {
-    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = 16;
+    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = KR ? 10 : 16;
     // operand groups requested ahead of use (6 MFMAs).  4 live groups x 3 fragments = 12 ring slots; with 16 a request
     // never lands on a fragment the two MFMAs just issued are still reading (hipcc would pad that hazard with an s_nop)
     constexpr int AHEAD = 3;
@@ -302,20 +314,22 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     //   g = 24 .. 31  dK^T[kb][db] += Q^T[s][db] dS[kb][s]    reads: two transposed 4-row blocks of Q
     // Group g + 3 is requested right before group g's MFMAs; groups 32 .. 34 are groups 0 .. 2 of the next block.
     s16x8 ring[RS];
+    s16x8 kreg[KR ? NKS : 1];   // KR: K rows of key block 0, lane (r, h): K[kw0 + r][16 ks + 8 h ..]
     f32x16 sacc[2], pacc[2];
     u32x4 pp[2][2], sp[2][2];
+    constexpr int F0 = KR ? 2 : 3;   // fragments a group of the S' chains requests
     struct G {
-        static constexpr int reads(int g) { return (g % 32) < 8 ? 3 : ((g % 32) < 16 ? 1 : 2); }
-        static constexpr int opidx(int g) { return (g % 32) < 8 ? 3 * (g % 32) : ((g % 32) < 16 ? 16 + (g % 32) : 16 + (g % 32)); }
+        static constexpr int reads(int g) { return (g % 32) < 8 ? (KR ? 2 : 3) : ((g % 32) < 16 ? 1 : 2); }
+        static constexpr int opidx(int g) { return (g % 32) < 8 ? (KR ? 2 : 3) * (g % 32) : 8 * (KR ? 2 : 3) - 8 + (g % 32); }
         static constexpr int slot(int g) { return opidx(g) % RS; }
     };
-    static_assert(G::opidx(8) == 24 && G::opidx(16) == 32 && G::opidx(31) == 47 && 48 % RS == 0, "ring bookkeeping");
+    static_assert(G::opidx(8) == 8 * F0 && G::opidx(31) == 8 * F0 + 23 && (8 * F0 + 24) % RS == 0, "ring bookkeeping");
     auto fetch = [&](auto gc) {
         constexpr int g = decltype(gc)::value % 32, ph = g / 8, i = g % 8, s0 = G::slot(g);
         if constexpr (ph == 0) {
             ring[s0] = lds_b128_asm<0>(qaddr[i]);
-            ring[(s0 + 1) % RS] = lds_b128_asm<0>(kaddr[i]);
-            ring[(s0 + 2) % RS] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
+            if constexpr (!KR) ring[(s0 + 1) % RS] = lds_b128_asm<0>(kaddr[i]);
+            ring[(s0 + F0 - 1) % RS] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
         } else if constexpr (ph == 1) {
             ring[s0] = lds_b128_asm<QT>(qaddr[i]);
         } else {
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             // first operand of the MFMAs, second operand / accumulator of key block 0 and 1
             const s16x8 opa = ring[s0];
             s16x8 opb0, opb1;
-            if constexpr (ph == 0) { opb0 = ring[(s0 + 1) % RS]; opb1 = ring[(s0 + 2) % RS]; }
+            if constexpr (ph == 0) { opb0 = KR ? kreg[KR ? i : 0] : ring[(s0 + 1) % RS]; opb1 = ring[(s0 + F0 - 1) % RS]; }
             else if constexpr (ph == 1) { opb0 = vf[0][i]; opb1 = vf[1][i]; }
             else if constexpr (ph == 2) { opb0 = *reinterpret_cast<s16x8*>(&pp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&pp[1][i / 4]); }
             else { opb0 = *reinterpret_cast<s16x8*>(&sp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&sp[1][i / 4]); }
@@ -426,6 +440,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             if constexpr (ABL & 4) {
                 if constexpr (ph < 2) M::v(opa, opb0, acc0);
                 else M::a(opa, opb0, acc0);
+            } else if constexpr (ph2 == 0 && KR) {
+                if constexpr (ph < 2) M::template f2_v<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], opa, opb0, acc0);
+                else M::template f2_a<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], opa, opb0, acc0);
             } else if constexpr (ph2 == 0) {
                 if constexpr (ph < 2) M::template fa_v<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], ring[(t0 + 2) % RS], opa, opb0, acc0);
                 else M::template fa_a<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], ring[(t0 + 2) % RS], opa, opb0, acc0);
@@ -497,6 +514,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     }
     dma_wait_all();
     __syncthreads();
+    if constexpr (KR) {   // the K tile has landed: this lane's fragments of key block 0 (compiler-visible reads: hipcc waits before their first use)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kreg[ks] = lds_b128_at(kaddr[ks]);
+    }
     // the V fragments are first used inside the stream: make hipcc wait for them here, not in the loop (its vmcnt wait
     // there would also drain the LDS-DMA of the tiles in flight)
 #pragma unroll
@@ -600,7 +621,10 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
                            (uint16_t*)ds, ds_tile_rows(a.n), ds_tile_cols(nk));
         return hipGetLastError();
     };
-    if (ds) return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>) : launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true>);
+    // K rows of key block 0 in registers: the non-causal kernels (option dkdv_kreg = 2: the round-2 form with 48 reads per block)
+    const bool kr = option(OPT_DKDV_KREG) != 2;
+    if (ds) return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>)
+                            : (kr ? launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, true>) : launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true>));
     if constexpr (std::is_same<Tag, bf16_tag>::value) {
         if (!a.causal) switch (option(OPT_DKDV_ABL)) {   // profiling ablations: see the kernel's header comment
             case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 1>);
@@ -621,7 +645,8 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
             default: break;
         }
     }
-    return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true>) : launch(bwd_dkdv_w4_kernel<Tag, false>);
+    if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true>);
+    return kr ? launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, true>) : launch(bwd_dkdv_w4_kernel<Tag, false>);
 }
 
 bool bwd_dkdv_w4_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
