@@ -372,8 +372,7 @@ def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
     tol = dtype_tolerances(torch.bfloat16)
     for a, b in zip(grads, (rq, rk, rv)):
         torch.testing.assert_close(a[:2].cpu(), b, **tol)
-    for a, b in zip(grads, (rq, rk, rv)):   # and the last units (the chunk loop's offsets into the key-side tensors)
-        pass
+    # and the last unit (the chunk loop's offsets into the key-side tensors)
     rq2, rk2, rv2, _, _ = orc.extended_attention_backward(q[-1:], k[-1:], v[-1:], do[-1:], causal=False, softmax_scale=scale)
     for a, b in zip(grads, (rq2, rk2, rv2)):
         torch.testing.assert_close(a[-1:].cpu(), b, **tol)
