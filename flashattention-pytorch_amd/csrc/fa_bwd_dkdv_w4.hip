@@ -56,6 +56,10 @@ namespace fa {
             asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" WAIT("%6") OPC " %1, %3, %4, %1"             \
                          : "=&v"(r0), "+v"(c) : "v"(qa), "v"(a), "v"(b), "n"(OFF), "n"(N));                             \
         }                                                                                                               \
+        template <int N, int OFF> static __device__ __forceinline__ void fb_a(unsigned qa, s16x8& r0, s16x8 a, s16x8 b, f32x16& c) { \
+            asm volatile("ds_read_b128 %0, %2 offset:%5\n\t" WAIT("%6") OPC " %1, %3, %4, %1"             \
+                         : "=&v"(r0), "+a"(c) : "v"(qa), "v"(a), "v"(b), "n"(OFF), "n"(N));                             \
+        }                                                                                                               \
         template <int N, int OFF> static __device__ __forceinline__ void ft_v(unsigned lo_a, unsigned hi_a, s16x4& lo, s16x4& hi, s16x8 a, s16x8 b, f32x16& c) { \
             asm volatile("ds_read_b64_tr_b16 %0, %3 offset:%7\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t" WAIT("%8") OPC " %2, %5, %6, %2" \
                          : "=&v"(lo), "=&v"(hi), "+v"(c) : "v"(lo_a), "v"(hi_a), "v"(a), "v"(b), "n"(OFF), "n"(N));     \
@@ -216,10 +220,11 @@ constexpr Op kSched[64][kWidth] = {
 // workgroup 16 KiB.  Element j of lane (r, h) is query 16 s + 8 (j >> 2) + 4 h + (j & 3) of the block (the accumulator's
 // register order); fa_bwd_dq_ds.hip reads the tiles back transposed (ds_read_b64_tr_b16).  Blocks the causal mask removes
 // whole (queries before the wave's first key) are never written; masked elements of the others are written as 0.
-// KR (round 3): the K rows of the wave's FIRST key block stay in 32 registers (the non-causal kernels have 46 spare), so a group of
-// the S' chains requests two fragments instead of three: 40 LDS operand reads per block instead of 48 (0.625 KB per MFMA instead
-// of 0.75), a 10-slot operand ring instead of 16.
-template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1), bool DS = false, bool KR = false>
+// KR (round 3): K rows in registers — the non-causal kernels run at 210 VGPRs with none there, and the operand ring shrinks as the
+// S' groups request fewer fragments, so there is room for all of them: KR = 1 key block 0 (2 fragments per S' group, 10-slot ring),
+// 2 + four fragments of block 1 (12 slots), 3 every K fragment (Q rows only, 8 slots): 32 operand fragments per block from LDS
+// instead of 48 (0.5 KB per MFMA instead of 0.75), 250 - 252 VGPRs, no scratch.
+template <typename Tag, bool CAUSAL, int ABL = 0, int TPW = (CAUSAL ? 2 : 1), bool DS = false, int KR = 0>
 __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                              const uint16_t* __restrict__ v,
                                                              const uint16_t* __restrict__ dout,
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                                                              uint16_t* __restrict__ dv, int n, int nkt, float c_log2,
                                                              float scale, int nk /* keys; n = query rows; causal: nk >= n, diagonal at key = row + nk - n */,
                                                              uint16_t* __restrict__ ds = nullptr, int nqb = 0, int nkb32 = 0 /* DS: tile grid of the dS workspace */) {
-    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, RS = KR ? 10 : 16;
+    constexpr int D = 128, NKS = 8, NDB = 4, BK = 256, BQ = 32, NBUF = 4, K1R = KR == 3 ? 8 : (KR == 2 ? 4 : 0), RS = KR == 3 ? 8 : (KR == 2 ? 12 : (KR ? 10 : 16));
     // operand groups requested ahead of use (6 MFMAs).  4 live groups x 3 fragments = 12 ring slots; with 16 a request
     // never lands on a fragment the two MFMAs just issued are still reading (hipcc would pad that hazard with an s_nop)
     constexpr int AHEAD = 3;
@@ -315,21 +320,28 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // Group g + 3 is requested right before group g's MFMAs; groups 32 .. 34 are groups 0 .. 2 of the next block.
     s16x8 ring[RS];
     s16x8 kreg[KR ? NKS : 1];   // KR: K rows of key block 0, lane (r, h): K[kw0 + r][16 ks + 8 h ..]
+    s16x8 kreg1[K1R ? K1R : 1]; // KR = 2: K rows of key block 1, k-steps 0 .. 3
     f32x16 sacc[2], pacc[2];
     u32x4 pp[2][2], sp[2][2];
-    constexpr int F0 = KR ? 2 : 3;   // fragments a group of the S' chains requests
+    // fragments a group of the S' chains requests: Q rows, + K rows of block 0 unless they are in registers (KR), + K rows of
+    // block 1 unless they are (KR = 2, k-steps 0 .. 3)
     struct G {
-        static constexpr int reads(int g) { return (g % 32) < 8 ? (KR ? 2 : 3) : ((g % 32) < 16 ? 1 : 2); }
-        static constexpr int opidx(int g) { return (g % 32) < 8 ? (KR ? 2 : 3) * (g % 32) : 8 * (KR ? 2 : 3) - 8 + (g % 32); }
+        static constexpr int f0(int i) { return 1 + (KR ? 0 : 1) + ((KR >= 2 && i < (KR == 3 ? 8 : 4)) ? 0 : 1); }
+        static constexpr int reads(int g) { return (g % 32) < 8 ? f0(g % 32) : ((g % 32) < 16 ? 1 : 2); }
+        static constexpr int opidx(int g) {
+            int s = 0;
+            for (int i = 0; i < ((g % 32) < 8 ? (g % 32) : 8); ++i) s += f0(i);
+            return (g % 32) < 8 ? s : s + (g % 32) - 8;
+        }
         static constexpr int slot(int g) { return opidx(g) % RS; }
     };
-    static_assert(G::opidx(8) == 8 * F0 && G::opidx(31) == 8 * F0 + 23 && (8 * F0 + 24) % RS == 0, "ring bookkeeping");
+    static_assert((G::opidx(31) + 1) % RS == 0, "ring bookkeeping: a block's operand slots must be a multiple of the ring");
     auto fetch = [&](auto gc) {
         constexpr int g = decltype(gc)::value % 32, ph = g / 8, i = g % 8, s0 = G::slot(g);
         if constexpr (ph == 0) {
             ring[s0] = lds_b128_asm<0>(qaddr[i]);
             if constexpr (!KR) ring[(s0 + 1) % RS] = lds_b128_asm<0>(kaddr[i]);
-            ring[(s0 + F0 - 1) % RS] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
+            if constexpr (i >= K1R) ring[(s0 + G::f0(i) - 1) % RS] = lds_b128_asm<32 * 2 * D>(kaddr[i]);
         } else if constexpr (ph == 1) {
             ring[s0] = lds_b128_asm<QT>(qaddr[i]);
         } else {
@@ -431,7 +443,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             // first operand of the MFMAs, second operand / accumulator of key block 0 and 1
             const s16x8 opa = ring[s0];
             s16x8 opb0, opb1;
-            if constexpr (ph == 0) { opb0 = KR ? kreg[KR ? i : 0] : ring[(s0 + 1) % RS]; opb1 = ring[(s0 + F0 - 1) % RS]; }
+            if constexpr (ph == 0) {
+                opb0 = KR ? kreg[KR ? i : 0] : ring[(s0 + 1) % RS];
+                opb1 = i < K1R ? kreg1[i < K1R ? i : 0] : ring[(s0 + G::f0(i) - 1) % RS];
+            }
             else if constexpr (ph == 1) { opb0 = vf[0][i]; opb1 = vf[1][i]; }
             else if constexpr (ph == 2) { opb0 = *reinterpret_cast<s16x8*>(&pp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&pp[1][i / 4]); }
             else { opb0 = *reinterpret_cast<s16x8*>(&sp[0][i / 4]); opb1 = *reinterpret_cast<s16x8*>(&sp[1][i / 4]); }
@@ -440,6 +455,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             if constexpr (ABL & 4) {
                 if constexpr (ph < 2) M::v(opa, opb0, acc0);
                 else M::a(opa, opb0, acc0);
+            } else if constexpr (ph2 == 0 && i2 < K1R) {   // Q rows only
+                if constexpr (ph < 2) M::template fb_v<NWAIT, 0>(qaddr[i2], ring[t0], opa, opb0, acc0);
+                else M::template fb_a<NWAIT, 0>(qaddr[i2], ring[t0], opa, opb0, acc0);
             } else if constexpr (ph2 == 0 && KR) {
                 if constexpr (ph < 2) M::template f2_v<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], opa, opb0, acc0);
                 else M::template f2_a<NWAIT>(qaddr[i2], kaddr[i2], ring[t0], ring[(t0 + 1) % RS], opa, opb0, acc0);
@@ -517,6 +535,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     if constexpr (KR) {   // the K tile has landed: this lane's fragments of key block 0 (compiler-visible reads: hipcc waits before their first use)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) kreg[ks] = lds_b128_at(kaddr[ks]);
+#pragma unroll
+        for (int ks = 0; ks < K1R; ++ks) kreg1[ks] = lds_b128_at(kaddr[ks] + 32 * 2 * D);
     }
     // the V fragments are first used inside the stream: make hipcc wait for them here, not in the loop (its vmcnt wait
     // there would also drain the LDS-DMA of the tiles in flight)
@@ -621,10 +641,20 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
                            (uint16_t*)ds, ds_tile_rows(a.n), ds_tile_cols(nk));
         return hipGetLastError();
     };
-    // K rows of key block 0 in registers: the non-causal kernels (option dkdv_kreg = 2: the round-2 form with 48 reads per block)
-    const bool kr = option(OPT_DKDV_KREG) != 2;
-    if (ds) return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>)
-                            : (kr ? launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, true>) : launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true>));
+    // K rows in registers: the non-causal kernels keep ALL of the wave's K fragments there (KR = 3: 250 - 252 VGPRs, no scratch;
+    // 1.738 ms per launch against 1.744 with block 0 + half of block 1, 1.751 with block 0 only, 1.781 with none, interleaved).
+    // Option dkdv_kreg: 2 = none (the round-2 form), 3 = key block 0 only, 4 = block 0 + four fragments of block 1.
+    const int kro = option(OPT_DKDV_KREG);
+    const int kr = kro == 2 ? 0 : (kro == 3 ? 1 : (kro == 4 ? 2 : 3));
+    if (ds) {
+        if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>);
+        switch (kr) {
+            case 0: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 0>);
+            case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 1>);
+            case 2: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 2>);
+            default: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 3>);
+        }
+    }
     if constexpr (std::is_same<Tag, bf16_tag>::value) {
         if (!a.causal) switch (option(OPT_DKDV_ABL)) {   // profiling ablations: see the kernel's header comment
             case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 1>);
@@ -646,7 +676,12 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
         }
     }
     if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true>);
-    return kr ? launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, true>) : launch(bwd_dkdv_w4_kernel<Tag, false>);
+    switch (kr) {
+        case 0: return launch(bwd_dkdv_w4_kernel<Tag, false>);
+        case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, 1>);
+        case 2: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, 2>);
+        default: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, 3>);
+    }
 }
 
 bool bwd_dkdv_w4_supported(int dtype, int64_t d) { return (dtype == 1 || dtype == 2) && d == 128; }
