@@ -285,7 +285,7 @@ static hipError_t launch_dkdv_t(const BwdArgs& a, const float* nlse, const float
         return hipGetLastError();
     };
     if constexpr (D == 64 && !PAD && !W4) {
-        if (option(OPT_DKDV_KREG) != 0) {
+        if (option(OPT_DKDV_KREG) == 1) {
             grid = dim3((unsigned)(nkt * a.bh));   // (one tile per workgroup: the variant has no pairing; until round 2 the causal sweep ran it on half a grid)
             return a.causal ? launch(bwd_dkdv_mfma_kernel<Tag, D, true, true, 1, PAD, W4>) : launch(bwd_dkdv_mfma_kernel<Tag, D, false, true, 1, PAD, W4>);
         }
@@ -307,7 +307,7 @@ hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float
     // the mask the stream kernel wins at every size: profiles/r02_small_launches.md).
     // Option dkdv: 5 = always the stream kernel, 8 = the 8-wave kernel.
     const int dk_opt = option(OPT_DKDV);
-    const bool sweeping = option(OPT_DKDV_KREG) || option(OPT_DKDV_TPW) || option(OPT_DKDV_STG);
+    const bool sweeping = option(OPT_DKDV_KREG) == 1 || option(OPT_DKDV_TPW) || option(OPT_DKDV_STG);   // (dkdv_kreg >= 2: forms of the stream kernel)
     if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && (a.causal ? !small_grid(a.bh, a.n, true) && a.n > 1024 : true))))   // (causal rows of <= 1024: the 8-wave kernel is 1 - 5 % ahead)
         return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
@@ -318,7 +318,7 @@ hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float
         if (a.dtype == 2) return a.d > 64 ? launch_dkdv_t<bf16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, true>(a, nlse, ndelta, st);
         return a.d > 64 ? launch_dkdv_t<f16_tag, 128, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, true>(a, nlse, ndelta, st);
     }
-    if (option(OPT_DKDV_KREG) == 0 && option(OPT_DKDV_TPW) == 0 && small_grid(a.bh, a.n, true)) {   // 128-key tiles on 4 waves
+    if (option(OPT_DKDV_KREG) != 1 && option(OPT_DKDV_TPW) == 0 && small_grid(a.bh, a.n, true)) {   // 128-key tiles on 4 waves
         if (a.dtype == 2) return a.d == 128 ? launch_dkdv_t<bf16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 64, false, true>(a, nlse, ndelta, st);
         return a.d == 128 ? launch_dkdv_t<f16_tag, 128, false, true>(a, nlse, ndelta, st) : launch_dkdv_t<f16_tag, 64, false, true>(a, nlse, ndelta, st);
     }

@@ -307,7 +307,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
 
     s16x8 vf[2][NKS];
     f32x16 dka[2][NDB], dva[2][NDB];
-    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
     unsigned kaddr[NKS], qaddr[NKS], tlo[NDB], thi[NDB], laddr;
     // first block this wave computes: earlier ones hold only queries before its first key (causal)
     int fb = 0;
@@ -497,11 +496,17 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     nblk = (n - qs_first + BQ - 1) / BQ;
     if (DS) dsp = (unsigned long long)(uintptr_t)ds + (((unsigned long long)bh * nqb + qs_first / BQ + fb) * nkb32 + (kw0 >> 5)) * 2048ull;
     // ---- prologue of a key tile: K tile, V fragments (B operand of dP = dO V^T), query tiles 0 .. 2
-    dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, dma_voff, w);
+    // TPW > 1: the lane-constant address arithmetic of the prologue and the epilogue does not depend on the tile, and hipcc
+    // would hoist it out of the tile loop and keep ~40 registers of it alive through the stream (256 VGPRs + scratch);
+    // an opaque copy of the lane id per tile keeps it where it is used
+    int lane_p = lane;
+    if (TPW > 1) asm volatile("" : "+v"(lane_p));
+    const int r_p = lane_p & 31, h_p = lane_p >> 5;
+    dma_stage_tile<D, BK, 4>(k_rs, Ks, key0, TPW > 1 ? dma_lane_voff<D>(lane_p, w, D) : dma_voff, w);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[kb][ks] = buf_load_frag(v_rs, frag_off(kw0 + 32 * kb + r, 16 * ks + 8 * h, D, false));
+        for (int ks = 0; ks < NKS; ++ks) vf[kb][ks] = buf_load_frag(v_rs, frag_off(kw0 + 32 * kb + r_p, 16 * ks + 8 * h_p, D, false));
     stage(0);
     stage(1);
     stage(2);
@@ -516,19 +521,20 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // (the swizzle depends on the row modulo 16 only).  The tile addresses move from buffer to buffer during the stream.
     {
         const unsigned kbase = lds_addr_of(Ks) + 64 * w * 2 * D, b0 = bbase + (fb & (NBUF - 1)) * BUF;
+        const int li = lane_p & 15, g16 = (lane_p >> 4) & 1, tq = li >> 2, tp = li & 3;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const int off = TileSwz<D>::off(r, 2 * ks + h);
+            const int off = TileSwz<D>::off(r_p, 2 * ks + h_p);
             kaddr[ks] = kbase + off;
             qaddr[ks] = b0 + off;
         }
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
             const int ch = 4 * db + 2 * g16 + (tp >> 1);
-            tlo[db] = b0 + TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
-            thi[db] = b0 + TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
+            tlo[db] = b0 + TileSwz<D>::off(4 * h_p + tq, ch) + 8 * (tp & 1);
+            thi[db] = b0 + TileSwz<D>::off(4 * h_p + tq + 8, ch) + 8 * (tp & 1);
         }
-        laddr = b0 + 2 * QT + 16 * h;
+        laddr = b0 + 2 * QT + 16 * h_p;
     }
     dma_wait_all();
     __syncthreads();
@@ -592,6 +598,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     // a wave only ever read its own 64 K rows: that slice of the K tile is its staging area for whole-row stores
     char* stg = Ks + w * 64 * D * 2;
+    int lane_e = lane;
+    if (TPW > 1) asm volatile("" : "+v"(lane_e));
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         u32x2 vals[NDB * 4];
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                 vals[4 * db + g][0] = pack2_rn<Tag>(dka[kb][db][4 * g + 0] * scale, dka[kb][db][4 * g + 1] * scale);
                 vals[4 * db + g][1] = pack2_rn<Tag>(dka[kb][db][4 * g + 2] * scale, dka[kb][db][4 * g + 3] * scale);
             }
-        store_rows_via_lds<D>(stg, vals, dk + kvbase, kw0 + 32 * kb, nk, lane, D);
+        store_rows_via_lds<D>(stg, vals, dk + kvbase, kw0 + 32 * kb, nk, lane_e, D);
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                 vals[4 * db + g][0] = pack2_rn<Tag>(dva[kb][db][4 * g + 0], dva[kb][db][4 * g + 1]);
                 vals[4 * db + g][1] = pack2_rn<Tag>(dva[kb][db][4 * g + 2], dva[kb][db][4 * g + 3]);
             }
-        store_rows_via_lds<D>(stg + 32 * D * 2, vals, dv + kvbase, kw0 + 32 * kb, nk, lane, D);
+        store_rows_via_lds<D>(stg + 32 * D * 2, vals, dv + kvbase, kw0 + 32 * kb, nk, lane_e, D);
     }
     if (TPW > 1) __syncthreads();   // the K tile and the query-tile buffers are about to be refilled
     }   // key tiles of this workgroup
@@ -641,13 +649,20 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
                            (uint16_t*)ds, ds_tile_rows(a.n), ds_tile_cols(nk));
         return hipGetLastError();
     };
-    // K rows in registers: the non-causal kernels keep ALL of the wave's K fragments there (KR = 3: 250 - 252 VGPRs, no scratch;
-    // 1.738 ms per launch against 1.744 with block 0 + half of block 1, 1.751 with block 0 only, 1.781 with none, interleaved).
+    // K rows in registers: the kernels keep ALL of the wave's K fragments there (KR = 3: 250 - 256 VGPRs, no scratch;
+    // non-causal 1.738 ms per launch against 1.744 with block 0 + half of block 1, 1.751 with block 0 only, 1.781 with none,
+    // interleaved; config 3 (causal) 3.294 / 3.296 / 3.323 / 3.367).
     // Option dkdv_kreg: 2 = none (the round-2 form), 3 = key block 0 only, 4 = block 0 + four fragments of block 1.
     const int kro = option(OPT_DKDV_KREG);
     const int kr = kro == 2 ? 0 : (kro == 3 ? 1 : (kro == 4 ? 2 : 3));
     if (ds) {
-        if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true>);
+        // (causal + dS stores + f16: KR = 3 is one register over — 16 bytes of scratch, 1.092 against 1.066 ms: KR = 2 there)
+        if (a.causal) switch ((kr == 3 && std::is_same<Tag, f16_tag>::value) ? 2 : kr) {
+            case 0: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true, 0>);
+            case 1: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true, 1>);
+            case 2: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true, 2>);
+            default: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, true, 3>);
+        }
         switch (kr) {
             case 0: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 0>);
             case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, true, 1>);
@@ -675,7 +690,12 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
             default: break;
         }
     }
-    if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true>);
+    if (a.causal) switch (kr) {
+        case 0: return launch(bwd_dkdv_w4_kernel<Tag, true>);
+        case 1: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, false, 1>);
+        case 2: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, false, 2>);
+        default: return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 2, false, 3>);
+    }
     switch (kr) {
         case 0: return launch(bwd_dkdv_w4_kernel<Tag, false>);
         case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 0, 1, false, 1>);

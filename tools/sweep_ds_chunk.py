@@ -25,7 +25,7 @@ def main():
     d, n, bh = 128, args.seqlen, args.bh
     g = torch.Generator(device="cuda").manual_seed(0)
     q, k, v, do = (torch.randn((bh, n, d), device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(4))
-    variants = [("recompute (dq=5)", {"dq": 5})] + [(f"chunk {mb} MiB", {"ds_chunk_mb": mb}) for mb in args.chunks]
+    variants = [("recompute (dq=5)", {"dq": 5})] + [(f"chunk {mb} MiB", {"ds_chunk_mb": mb, **({"dq": 6} if args.causal else {})}) for mb in args.chunks]   # (causal: the hand-over only by option)
     res = {name: [] for name, _ in variants}
     wsb = {}
     kern = {name: {} for name, _ in variants}
@@ -34,7 +34,7 @@ def main():
             for key in ("dq", "ds_chunk_mb"):
                 ext.set_option(key, opts.get(key, 0))
             ext.release_workspace()
-            wsb[name] = int(ext._lib.fa_backward_workspace_bytes_fast(bh, n, d, 2, int(args.causal))) if "dq" not in opts \
+            wsb[name] = int(ext._lib.fa_backward_workspace_bytes_fast(bh, n, d, 2, int(args.causal))) if opts.get("dq") != 5 \
                 else int(ext._lib.fa_backward_workspace_bytes(bh, n, d, 2))
             for _ in range(2):
                 o, lse = ext.forward(q, k, v, args.causal, d ** -0.5, 64, 128)
