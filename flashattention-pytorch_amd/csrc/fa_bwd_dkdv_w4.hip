@@ -111,6 +111,7 @@ template <int OFF> __device__ __forceinline__ void lds_acc_init_asm(unsigned add
 // ABL != 0: profiling ablations (wrong results on purpose; option dkdv_abl):
 //   bit 0: no vector slices (P, dS)   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no LDS operand requests
 //   bit 3: no row-constant loads      bit 4: no address updates
+//   bit 6: (DS variant) no dS stores
 //   bit 5: shader-clock stamps around the block loop; wave 0 of workgroup 0 overwrites dk[0..7] with
 //          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py)
 // LDS-DMA pieces of the stream: the LDS address and the soffset come from scalar arithmetic on kernel arguments and the
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // the real ones; not waiting for them saves nothing; in the nearly empty gaps of the dP' chains they cost the same:
     // profiles/r02_ds_handover.md) — about a third of it in cycles, the rest in clock: the chip is power-limited.
     auto wait_tiles = [&](bool first_block = false) {
-        if (!DS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (!DS || (ABL & 64)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (ABL & 128) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");   // experiment: only the tile the next block reads
         else if (first_block) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
     };
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             }
         }
     };
+    unsigned long long tq[8] = {};
     auto block = [&](int blk) {
         const int dlt = ((blk + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
         // Vector work, cut into single instructions' worth and placed by the table above (w4sched::kSched): MUL + EXP: one
@@ -401,7 +404,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         };
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr (DS && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});
+            if constexpr ((ABL & 8192) != 0 && (S % 8) == 7) asm volatile("s_memtime %0" : "=s"(tq[S / 8]));   // experiment: eight stamps inside the block
+            if constexpr (DS && !(ABL & 64) && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});
             {   // ABL bits: see the kernel's header comment
                 for_each_const([&](auto jc) {
                     constexpr w4sched::Op o = w4sched::kSched[S][decltype(jc)::value];
@@ -516,6 +520,11 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         for (int t = 0; t < NDB; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dka[kb][t][i] = 0.f; dva[kb][t][i] = 0.f; }
+    // pin the zeroing HERE, under the prologue's loads: hipcc sinks it to the stream's entry otherwise — 256 v_accvgpr_write
+    // (2 500 cycles) between a wave's last feed-only barrier and its first block, with the other waves waiting at the next barrier
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+        asm volatile("" : "+a"(dka[kb][0]), "+a"(dka[kb][1]), "+a"(dka[kb][2]), "+a"(dka[kb][3]), "+a"(dva[kb][0]), "+a"(dva[kb][1]), "+a"(dva[kb][2]), "+a"(dva[kb][3]));
     // lane-constant operand addresses (LDS bytes).  Q / dO rows and K rows: row r, chunk 2 ks + h; transposed reads:
     // 4-row blocks at rows 4 h + tq (+8), chunks 4 db + 2 g16 + (tp >> 1); everything else is an immediate offset
     // (the swizzle depends on the row modulo 16 only).  The tile addresses move from buffer to buffer during the stream.
@@ -552,34 +561,70 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         for (int ks = 0; ks < NKS; ks += 4)
             asm volatile("" : "+v"(vf[kb][ks]), "+v"(vf[kb][ks + 1]), "+v"(vf[kb][ks + 2]), "+v"(vf[kb][ks + 3]));
 
-    // feed-only blocks (causal: queries before this wave's first key): the wave's share of the LDS-DMA and the barriers
-    for (int blk = 0; blk < min(fb, nblk); ++blk) {
-        stage(blk + 3);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // (no stores here: the count of the plain kernel)
-        __builtin_amdgcn_s_barrier();
+    // feed-only blocks (causal: queries before this wave's first key): the wave's share of the LDS-DMA and the barriers.
+    // The set-up of the wave's first block — row constants into the accumulators, the mask, operand groups 0 .. 2 in flight —
+    // sits in FRONT of the last feed-only barrier (tile fb is visible since the barrier of iteration fb - 2, or since the
+    // prologue when fb <= 2): behind it the other waves, already streaming, would wait for the late starter at the next barrier.
+    const int nfeed = min(fb, nblk);
+    for (int blk = 0;; ++blk) {
+        const bool last = blk >= nfeed - 1;   // (also when there is no feed-only block)
+        if (blk < nfeed) stage(blk + 3);
+        if ((ABL & 4096) && last && blk < nfeed && fb < nblk) {   // experiment: matrix pipe warm-up ahead of the wave's first block
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                W4Stream<Tag, false>::v(vf[0][i & 7], vf[1][i & 7], sacc[0]);
+                W4Stream<Tag, false>::v(vf[1][i & 7], vf[0][i & 7], sacc[1]);
+            }
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc[0]), "+v"(sacc[1]));
+        }
+        if (last && fb < nblk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts are exact
+            lds_acc_init<0>(laddr, sacc[0]);
+            lds_acc_init<0>(laddr, sacc[1]);
+            mask_init(fb);
+            lds_acc_init<256>(laddr, pacc[0]);
+            lds_acc_init<256>(laddr, pacc[1]);
+            fetch(std::integral_constant<int, 0>{});
+            fetch(std::integral_constant<int, 1>{});
+            fetch(std::integral_constant<int, 2>{});
+        }
+        if (blk < nfeed) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // (no stores here: the count of the plain kernel)
+            __builtin_amdgcn_s_barrier();
+        }
+        if (last) break;
     }
     if (fb < nblk) {
-        // first block: row constants into the accumulators, operand groups 0 and 1 in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts are exact
-        lds_acc_init<0>(laddr, sacc[0]);
-        lds_acc_init<0>(laddr, sacc[1]);
-        mask_init(fb);
-        lds_acc_init<256>(laddr, pacc[0]);
-        lds_acc_init<256>(laddr, pacc[1]);
-        fetch(std::integral_constant<int, 0>{});
-        fetch(std::integral_constant<int, 1>{});
-        fetch(std::integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
         unsigned long long t_begin = 0;
         if (ABL & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
 #pragma unroll 1
         for (int blk = fb; blk < nblk; ++blk) {
             block(blk);
-            mask_init(blk + 1);   // on the next block's initial accumulators, outside the stream (the only branch)
-            if (DS) dsp += (unsigned long long)nkb32 * 2048;
+            if ((ABL & 8192) && L == 0 && blk < 8) {   // the in-block stamps of blocks 0 .. 7: dk[320 + 64 w + 8 blk + i]
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 8) {
+                    unsigned long long tv = tq[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) tv = lane == i ? tq[i] : tv;
+                    reinterpret_cast<unsigned*>(dk)[320 + 64 * w + 8 * blk + lane] = (unsigned)tv;
+                }
+            }
+            if ((ABL & 32) && L == 0 && blk < 24) {   // per-wave stamps of blocks 0 .. 23 of workgroup 0's last tile: own work done, dk[32 + 64 w + 2 blk]
+                unsigned long long t_now;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");
+                if (lane == 0) reinterpret_cast<unsigned*>(dk)[32 + 64 * w + 2 * blk] = (unsigned)t_now;
+            }
+            if (!(ABL & 2048)) mask_init(blk + 1);   // on the next block's initial accumulators, outside the stream (the only branch)
+            if (DS && !(ABL & 1024)) dsp += (unsigned long long)nkb32 * 2048;   // (1024: experiment — every block's stores land on the same 4 KiB)
             if (!(ABL & 2)) {
                 wait_tiles(blk == fb);
                 __builtin_amdgcn_s_barrier();
+            }
+            if ((ABL & 32) && L == 0 && blk < 24) {   // ... and behind the barrier: dk[32 + 64 w + 2 blk + 1]
+                unsigned long long t_now;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");
+                if (lane == 0) reinterpret_cast<unsigned*>(dk)[32 + 64 * w + 2 * blk + 1] = (unsigned)t_now;
             }
         }
         if (ABL & 32) {
@@ -595,6 +640,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                  : "+a"(dka[0][0]), "+a"(dka[0][1]), "+a"(dka[0][2]), "+a"(dka[0][3]), "+a"(dka[1][0]), "+a"(dka[1][1]),
                    "+a"(dka[1][2]), "+a"(dka[1][3]), "+a"(dva[0][0]), "+a"(dva[0][1]), "+a"(dva[0][2]), "+a"(dva[0][3]),
                    "+a"(dva[1][0]), "+a"(dva[1][1]), "+a"(dva[1][2]), "+a"(dva[1][3]));
+    if (DS && (ABL & 256)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // experiment: the last block's dS stores may stay in flight
+    else
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     // a wave only ever read its own 64 K rows: that slice of the K tile is its staging area for whole-row stores
     char* stg = Ks + w * 64 * D * 2;
@@ -639,7 +686,8 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
     const size_t smem = (size_t)BK * D * 2 + 4 * (2 * 32 * D * 2 + 1024);
     const float c = a.scale * 1.4426950408889634f;
     // key tiles per workgroup: 2 under the causal mask (heavy + light pair), else 1
-    dim3 grid((unsigned)((a.causal ? (nkt + 1) / 2 : nkt) * a.bh));
+    const bool tpw1 = a.causal && (option(OPT_DKDV_ABL) & 512);   // experiment: one key tile per workgroup under the mask too
+    dim3 grid((unsigned)((a.causal && !tpw1 ? (nkt + 1) / 2 : nkt) * a.bh));
     ProfScope ps(K_BWD_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
@@ -655,6 +703,30 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
     // Option dkdv_kreg: 2 = none (the round-2 form), 3 = key block 0 only, 4 = block 0 + four fragments of block 1.
     const int kro = option(OPT_DKDV_KREG);
     const int kr = kro == 2 ? 0 : (kro == 3 ? 1 : (kro == 4 ? 2 : 3));
+    if (ds && option(OPT_DKDV_ABL) >= 32) {
+        if constexpr (std::is_same<Tag, bf16_tag>::value) switch (option(OPT_DKDV_ABL)) {
+            case 64: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 64, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 64, 1, true, 3>);
+            case 128: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 128, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 128, 1, true, 3>);
+            case 256: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 256, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 256, 1, true, 3>);
+            case 384: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 384, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 384, 1, true, 3>);
+            case 1024: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 1024, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 1024, 1, true, 3>);
+            case 32: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 32, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 32, 1, true, 3>);
+            case 96: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 96, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 96, 1, true, 3>);
+            case 544: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 32, 1, true, 3>); break;
+            case 608: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 96, 1, true, 3>); break;
+            case 4192: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 4192, 2, true, 3>); break;   // stamps, no stores, warm-up
+            case 4096: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 4096, 2, true, 3>); break;
+            case 97: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 97, 2, true, 3>); break;
+            case 100: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 100, 2, true, 3>); break;
+            case 104: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 104, 2, true, 3>); break;
+            case 112: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 112, 2, true, 3>); break;
+            case 125: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 125, 2, true, 3>); break;
+            case 8317: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 8317, 2, true, 3>); break;
+            case 2080: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 2080, 2, true, 3>); break;   // stamps, no mask branch in the loop
+            case 512: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 1, true, 3>); break;
+            default: break;
+        }
+    }
     if (ds) {
         // (causal + dS stores + f16: KR = 3 is one register over — 16 bytes of scratch, 1.092 against 1.066 ms: KR = 2 there)
         if (a.causal) switch ((kr == 3 && std::is_same<Tag, f16_tag>::value) ? 2 : kr) {

@@ -42,14 +42,41 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
     constexpr int PIECES = KP + 4;                  // per wave and stage: K, 2 x 2 of dS
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // Under the causal mask a workgroup takes a PAIR of query tiles, qt and nqt - 1 - qt (the tile with the most keys and the one
+    // with the fewest): every workgroup then reads the same number of stages.  One tile per workgroup, most keys first, left the
+    // launch a tail of 12 - 15 % (list scheduling of jobs of 1 .. nqt units in (b,h)-major order).
+    constexpr int TPW = CAUSAL ? 2 : 1;
+    const int npair = (nqt + TPW - 1) / TPW;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = L / nqt;
-    const int qt = CAUSAL ? nqt - 1 - (L - bh * nqt) : L - bh * nqt;   // causal: the tiles with the most keys first
+    const int bh = L / npair;
+    const int jp = L - bh * npair;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qt * BM, q0w = q0 + 64 * w;
     const int coff = nk - n;
     const size_t kvbase = (size_t)bh * nk * D, base = (size_t)bh * n * D;
+    const rsrc_s_t k_rs = make_rsrc_s(k + kvbase, (unsigned)nk * D * 2);
+    const int k_voff = dma_lane_voff<D>(lane, w, D);
+    // dS tile, LDS chunk p = 64 i + lane of piece i holds [r >> 2][s][r & 3][h]: r = 16 i + 4 (lane >> 4) + ((lane >> 1) & 3),
+    // s = (lane >> 3) & 1, h = lane & 1; in memory it sits at 1024 s + 32 r + 16 h
+    const int s_voff = 1024 * ((lane >> 3) & 1) + 32 * (4 * (lane >> 4) + ((lane >> 1) & 3)) + 16 * (lane & 1);
+    const unsigned bbase = lds_addr_of(smem);
+    // lane-constant operand addresses inside a buffer (transposed reads: 4-row blocks at rows 4 h + tq (+ 8); the
+    // k-step and the query block are immediate offsets)
+    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+    unsigned klo[NDB], khi[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const int ch = 4 * db + 2 * g16 + (tp >> 1);
+        klo[db] = TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
+        khi[db] = TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
+    }
+    const unsigned slo = K_BYTES + w * DS_W + 256 * h + 128 * g16 + 32 * tq + 8 * tp;   // rows 4 h + tq; + 512: rows + 8
+
+#pragma unroll 1
+    for (int ip = 0; ip < TPW; ++ip) {
+    const int qt = CAUSAL ? (ip == 0 ? nqt - 1 - jp : jp) : jp;   // the long tile first
+    if (ip > 0 && qt >= nqt - 1 - jp) break;                      // odd tile count: the middle tile is its own pair
+    const int q0 = qt * BM, q0w = q0 + 64 * w;
 
     // stages of this workgroup; per wave and query block: is block (qb, stage t) one the dK/dV kernel wrote (and non-zero)?
     const int nst_all = (nk + SK - 1) / SK;
@@ -61,15 +88,9 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
         return !CAUSAL || 64 * (t >> 1) <= q0w + 32 * qb + 31 + coff;
     };
 
-    const rsrc_s_t k_rs = make_rsrc_s(k + kvbase, (unsigned)nk * D * 2);
     // the wave's two rows of dS tiles are neighbours in memory: one descriptor, rows that do not exist are never requested
     const int rows_here = max(0, min(2, nqb - qbi0));
     const rsrc_s_t s_rs = make_rsrc_s(ds + ((size_t)bh * nqb + min(qbi0, nqb - 1)) * nkb32 * 1024, (unsigned)(rows_here * nkb32) * 2048u);
-    const int k_voff = dma_lane_voff<D>(lane, w, D);
-    // dS tile, LDS chunk p = 64 i + lane of piece i holds [r >> 2][s][r & 3][h]: r = 16 i + 4 (lane >> 4) + ((lane >> 1) & 3),
-    // s = (lane >> 3) & 1, h = lane & 1; in memory it sits at 1024 s + 32 r + 16 h
-    const int s_voff = 1024 * ((lane >> 3) & 1) + 32 * (4 * (lane >> 4) + ((lane >> 1) & 3)) + 16 * (lane & 1);
-    const unsigned bbase = lds_addr_of(smem);
     auto stage = [&](int t) {
         const unsigned b = bbase + (unsigned)(t % NBUF) * BUF;
         const bool kl = t < nst;
@@ -95,18 +116,6 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) dqa[qb][db][i] = 0.f;
-
-    // lane-constant operand addresses inside a buffer (transposed reads: 4-row blocks at rows 4 h + tq (+ 8); the
-    // k-step and the query block are immediate offsets)
-    const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
-    unsigned klo[NDB], khi[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-        const int ch = 4 * db + 2 * g16 + (tp >> 1);
-        klo[db] = TileSwz<D>::off(4 * h + tq, ch) + 8 * (tp & 1);
-        khi[db] = TileSwz<D>::off(4 * h + tq + 8, ch) + 8 * (tp & 1);
-    }
-    const unsigned slo = K_BYTES + w * DS_W + 256 * h + 128 * g16 + 32 * tq + 8 * tp;   // rows 4 h + tq; + 512: rows + 8
 
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) stage(t);
@@ -156,6 +165,8 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
             }
         store_rows_via_lds<D>(smem + w * 32 * D * 2, vals, dq + base, q0w + 32 * qb, n, lane, D, prow);
     }
+    if (TPW > 1) __syncthreads();   // the staging rows are stage buffers again
+    }   // query tiles of this workgroup
 }
 
 template <typename Tag>
@@ -165,7 +176,7 @@ static hipError_t launch_dq_ds_t(const BwdArgs& a, const void* ds, hipStream_t s
     const int64_t nk = a.nk > 0 ? a.nk : a.n;
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = nw == 8 ? 3 * (32 * 128 * 2 + 8 * 4096) : 6 * (32 * 128 * 2 + 4 * 4096);
-    dim3 grid((unsigned)(nqt * a.bh));
+    dim3 grid((unsigned)((a.causal ? (nqt + 1) / 2 : nqt) * a.bh));   // causal: pairs of query tiles
     ProfScope ps(K_BWD_DQ_MFMA, st);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);

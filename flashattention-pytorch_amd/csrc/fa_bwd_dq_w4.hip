@@ -314,6 +314,8 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_w4_kernel(const uint16_t* __res
 #pragma unroll
             for (int i = 0; i < 16; ++i) dqa[qb][t][i] = 0.f;
     }
+    // (pinned here, under the loads in flight: hipcc sinks the zeroing of the resident accumulators behind the barrier otherwise)
+    asm volatile("" : "+a"(dqa[0][0]), "+a"(dqa[0][1]), "+a"(dqa[0][2]), "+a"(dqa[0][3]), "+a"(dqa[1][0]), "+a"(dqa[1][1]), "+a"(dqa[1][2]), "+a"(dqa[1][3]));
     mt_dirty = false;
     // key tiles 0 .. 2 of this query tile (the tile buffers are free: every wave is past the previous tile's last barrier)
     stage(0);

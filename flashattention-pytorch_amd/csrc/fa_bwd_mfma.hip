@@ -363,23 +363,29 @@ static size_t ds_chunk_bytes() {
     const int mb = option(OPT_DS_CHUNK_MB);
     return mb > 0 ? (size_t)mb << 20 : (size_t)4 << 30;
 }
+static int64_t ds_chunk_units(int64_t bh, int64_t n, int64_t nk = 0) {
+    const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, nk > 0 ? nk : n));
+    if (fit >= bh) return bh;
+    if (fit < 1) return 0;
+    const int64_t nch = (bh + fit - 1) / fit;
+    return (bh + nch - 1) / nch;   // equal chunks: a short last one would leave CUs idle
+}
 static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal, bool atomic_variant, int64_t nk = 0) {
     const int dq_opt = option(OPT_DQ), dkdv_opt = option(OPT_DKDV);
     if (atomic_variant || !bwd_dkdv_w4_supported(dtype, d)) return false;
     // a kernel pinned by option (A/B runs of one pass against another) keeps the other pass as it was: only dq = 6 asks for this path
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
-    if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || option(OPT_DKDV_ABL) || option(OPT_DQ_ABL)) return false;
+    if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || (option(OPT_DKDV_ABL) && option(OPT_DKDV_ABL) < 32) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, nk > 0 ? nk : n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
     // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
-    if (causal) return false;
-    return !small_grid(bh, n, true);
-}
-static int64_t ds_chunk_units(int64_t bh, int64_t n, int64_t nk = 0) {
-    const int64_t fit = (int64_t)(ds_chunk_bytes() / ds_workspace_bytes(1, n, nk > 0 ? nk : n));
-    if (fit >= bh) return bh;
-    const int64_t nch = (bh + fit - 1) / fit;
-    return (bh + nch - 1) / nch;   // equal chunks: a short last one would leave CUs idle
+    if (small_grid(bh, n, true)) return false;
+    // Under the causal mask (round 3, profiles/r03_causal_handover.md: the dQ product kernel pairs its query tiles, the dK/dV
+    // kernel's diagonal blocks no longer wait for late starters) the hand-over is 0 - 4 % ahead from rows of 2048 on, while a
+    // chunk holds 16 (b,h) units or the whole launch: below that its launches do not fill the chip (N = 16384: 8 units, -1 %);
+    // rows of <= 1024 keep the 8-wave dK/dV kernel.
+    if (causal) return n > 1024 && ds_chunk_units(bh, n, nk) >= (bh < 16 ? bh : 16);
+    return true;
 }
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {
     return row_constants_bytes(bh, n) + (atomic_variant ? sizeof(float) * (size_t)bh * n * d : 0) + 256;

@@ -823,24 +823,26 @@ def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device)
         assert max_abs(a.cpu(), b) < (2e-2 if dtype == torch.bfloat16 else 4e-3) * b.abs().max().item()
 
 
-def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_recomputing_pass(device):
+@pytest.mark.parametrize("causal", [False, True])
+def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_recomputing_pass(causal, device):
     """Config 4's per-GPU kind of launch (here 64 units: 64 x 16 row tiles): the default backward takes the dS hand-over (the
     library profile shows the preparation launch that only it has), dq = 5 the recomputing pass; same results up to summation
-    order; a workspace of the minimum size makes the library fall back by itself."""
+    order; a workspace of the minimum size makes the library fall back by itself.  Round 3: under the causal mask too (rows of
+    2048 and more, 16 units per chunk)."""
     import flashattention_lab_cuda as ext
 
     bh, n, d = 64, 4096, 128
     q, k, v, do = make_qkv(bh, n, d, torch.bfloat16, seed=11, device=device)
-    o, lse = ext.forward(q, k, v, False, d ** -0.5, 64, 128)
+    o, lse = ext.forward(q, k, v, causal, d ** -0.5, 64, 128)
     ext.profile_enable(True)
-    got = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+    got = ext.backward(q, k, v, o, do, lse, causal, d ** -0.5, 64, 128)
     torch.cuda.synchronize()
     prof = ext.profile_report()
     ext.profile_enable(False)
     assert "bwd_delta" in prof and "bwd_dq_mfma" in prof and "bwd_mfma" in prof, prof
     ext.set_option("dq", 5)
     try:
-        ref = ext.backward(q, k, v, o, do, lse, False, d ** -0.5, 64, 128)
+        ref = ext.backward(q, k, v, o, do, lse, causal, d ** -0.5, 64, 128)
     finally:
         ext.set_option("dq", 0)
     for a, b in zip(got, ref):
@@ -857,7 +859,7 @@ def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_re
     dq2, dk2, dv2 = (torch.empty_like(t) for t in (q, k, v))
     ext.profile_enable(True)
     rc = lib.fa2_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq2.data_ptr(),
-                          dk2.data_ptr(), dv2.data_ptr(), bh, n, d, 2, 0, d ** -0.5, 64, 128, ws.data_ptr(), nbytes,
+                          dk2.data_ptr(), dv2.data_ptr(), bh, n, d, 2, int(causal), d ** -0.5, 64, 128, ws.data_ptr(), nbytes,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     prof2 = ext.profile_report()
@@ -870,8 +872,8 @@ def test_ds_handover_is_the_default_at_the_headline_shape_and_agrees_with_the_re
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_memory_is_bounded_at_the_config4_shard(causal, device):
     """the backward's device memory at 256 x 4096 x 128 (config 4's per-GPU shard) is its three outputs + a
-    workspace that does not grow with BH or N: 4 GiB of dS tiles (two chunks of 128 units) + 8 MiB of row constants without the
-    mask, the 8 MiB alone under it (recomputing backward).  The workspace is the shim's persistent buffer: a second call
+    workspace that does not grow with BH or N: 4 GiB of dS tiles (two chunks of 128 units) + 8 MiB of row constants, with the
+    mask or without (round 3: the hand-over serves causal rows of 2048 and more too).  The workspace is the shim's persistent buffer: a second call
     allocates nothing but its outputs.  The reference keeps O(BH N d) scratch (csrc/fa2/fa2_bwd.cu:53-57)."""
     import flashattention_lab_cuda as ext
 
@@ -881,7 +883,7 @@ def test_backward_memory_is_bounded_at_the_config4_shard(causal, device):
     torch.cuda.synchronize()
     ext.release_workspace()
     tensor = bh * n * d * 2
-    bound = 3 * tensor + (0 if causal else 4 << 30) + (8 << 20) + (2 << 20)
+    bound = 3 * tensor + (4 << 30) + (8 << 20) + (2 << 20)
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
     ext.profile_enable(True)
@@ -891,11 +893,9 @@ def test_backward_memory_is_bounded_at_the_config4_shard(causal, device):
     ext.profile_enable(False)
     first = torch.cuda.max_memory_allocated() - base
     assert first <= bound, (first, bound)
-    assert ext.workspace_stats()["bytes"] <= (0 if causal else 4 << 30) + (9 << 20)
-    if not causal:   # the hand-over ran, in two chunks: one preparation launch, two dK/dV + dQ launch pairs
-        assert prof["bwd_delta"][0] == 1 and prof["bwd_mfma"][0] == 2 and prof["bwd_dq_mfma"][0] == 2, prof
-    else:
-        assert "bwd_delta" not in prof, prof
+    assert ext.workspace_stats()["bytes"] <= (4 << 30) + (9 << 20)
+    # the hand-over ran, in two chunks: one preparation launch, two dK/dV + dQ launch pairs
+    assert prof["bwd_delta"][0] == 1 and prof["bwd_mfma"][0] == 2 and prof["bwd_dq_mfma"][0] == 2, prof
     allocs = ext.workspace_stats()["allocations"]
     del dq, dk, dv
     torch.cuda.reset_peak_memory_stats()
