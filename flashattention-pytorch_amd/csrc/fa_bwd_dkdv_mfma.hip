@@ -308,7 +308,7 @@ hipError_t launch_bwd_dkdv_mfma(const BwdArgs& a, const float* nlse, const float
     // Option dkdv: 5 = always the stream kernel, 8 = the 8-wave kernel.
     const int dk_opt = option(OPT_DKDV);
     const bool sweeping = option(OPT_DKDV_KREG) == 1 || option(OPT_DKDV_TPW) || option(OPT_DKDV_STG);   // (dkdv_kreg >= 2: forms of the stream kernel)
-    if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && (a.causal ? !small_grid(a.bh, a.n, true) && a.n > 1024 : true))))   // (causal rows of <= 1024: the 8-wave kernel is 1 - 5 % ahead)
+    if (bwd_dkdv_w4_supported(a.dtype, a.d) && (dk_opt == 5 || (dk_opt == 0 && !sweeping && (a.causal ? !small_grid(a.bh, a.n, true) : true))))   // (round 3: causal rows of <= 1024 too — 8 - 10 % ahead of the 8-wave kernel since the stream kernel's wave starts were fixed)
         return launch_bwd_dkdv_w4(a, nlse, ndelta, st);
     if (a.d > 128) {   // 256-wide tiles, 4 waves (one per SIMD)
         if (a.dtype == 2) return a.d == 256 ? launch_dkdv_t<bf16_tag, 256, false>(a, nlse, ndelta, st) : launch_dkdv_t<bf16_tag, 256, true>(a, nlse, ndelta, st);

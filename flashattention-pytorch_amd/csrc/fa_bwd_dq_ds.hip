@@ -171,9 +171,13 @@ __global__ __launch_bounds__(64 * NW, 1) void bwd_dq_ds_kernel(const uint16_t* _
 
 template <typename Tag>
 static hipError_t launch_dq_ds_t(const BwdArgs& a, const void* ds, hipStream_t st) {
-    const int nw = option(OPT_DQ_W4) == 3 ? 4 : 8;   // (option dq_w4 = 3 with dq = 6: the 4-wave / 256-row form, for the sweep)
-    const int BM = 64 * nw;
+    // 512 query rows per workgroup (8 waves) while that makes at least 160 workgroups — pairs of tiles under the causal mask —
+    // else 256 rows (4 waves): 32 x 4096 causal 0.390 against 0.417 ms, 16 x 8192 0.725 against 0.761; 48 x 4096 the other
+    // way round, 0.637 against 0.675 (tools/bwd_variant_sweep.py).  Option dq_w4 = 3 forces the 4-wave form.
     const int64_t nk = a.nk > 0 ? a.nk : a.n;
+    const int64_t nqt8 = (a.n + 511) / 512;
+    const int nw = (option(OPT_DQ_W4) == 3 || (a.causal ? (nqt8 + 1) / 2 : nqt8) * a.bh < 160) ? 4 : 8;
+    const int BM = 64 * nw;
     const int nqt = (int)((a.n + BM - 1) / BM);
     const size_t smem = nw == 8 ? 3 * (32 * 128 * 2 + 8 * 4096) : 6 * (32 * 128 * 2 + 4 * 4096);
     dim3 grid((unsigned)((a.causal ? (nqt + 1) / 2 : nqt) * a.bh));   // causal: pairs of query tiles

@@ -380,11 +380,11 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
     if (small_grid(bh, n, true)) return false;
-    // Under the causal mask (round 3, profiles/r03_causal_handover.md: the dQ product kernel pairs its query tiles, the dK/dV
-    // kernel's diagonal blocks no longer wait for late starters) the hand-over is 0 - 4 % ahead from rows of 2048 on, while a
-    // chunk holds 16 (b,h) units or the whole launch: below that its launches do not fill the chip (N = 16384: 8 units, -1 %);
-    // rows of <= 1024 keep the 8-wave dK/dV kernel.
-    if (causal) return n > 1024 && ds_chunk_units(bh, n, nk) >= (bh < 16 ? bh : 16);
+    // Under the causal mask too (round 3, profiles/r03_causal_handover.md: the dQ product kernel pairs its query tiles, the
+    // dK/dV kernel's diagonal blocks no longer wait for late starters): 2 - 25 % ahead of the recomputing pass from 512 row tiles
+    // on — the short rows most, 2048 x 256: 0.37 against 0.49 ms — while a chunk holds 16 (b,h) units or the whole launch; below
+    // that its launches do not fill the chip (N = 16384: 8 units per chunk, -1 %).
+    if (causal) return ds_chunk_units(bh, n, nk) >= (bh < 16 ? bh : 16);
     return true;
 }
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {

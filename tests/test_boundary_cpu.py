@@ -52,12 +52,13 @@ def test_workspace_query_and_argument_validation_without_gpu():
     # mask, launches of > 256 row tiles), at most 4 GiB (equal chunks of (b,h) units); the minimum everywhere else
     base = lib.fa_backward_workspace_bytes(256, 4096, 128, 2)
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 0) == base + 128 * 4096 * 4096 * 2   # two chunks of 128 units
-    # causal (round 3): the hand-over from rows of 2048 on while a chunk holds 16 units (or the whole launch), else the recomputing backward
+    # causal (round 3): the hand-over too, while a chunk holds 16 units (or the whole launch), else the recomputing backward
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 2, 1) == base + 128 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(128, 8192, 128, 2, 1) == lib.fa_backward_workspace_bytes(128, 8192, 128, 2) + 32 * 8192 * 8192 * 2
     assert lib.fa_backward_workspace_bytes_fast(32, 16384, 128, 2, 1) == lib.fa_backward_workspace_bytes(32, 16384, 128, 2)    # 8 units per chunk: O(BH N) bytes
     assert lib.fa_backward_workspace_bytes_fast(8, 16384, 128, 2, 1) == lib.fa_backward_workspace_bytes(8, 16384, 128, 2) + 8 * 16384 * 16384 * 2
-    assert lib.fa_backward_workspace_bytes_fast(512, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(512, 1024, 128, 2)   # rows of <= 1024: the 8-wave dK/dV kernel
+    assert lib.fa_backward_workspace_bytes_fast(512, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(512, 1024, 128, 2) + 512 * 1024 * 1024 * 2   # short rows too
+    assert lib.fa_backward_workspace_bytes_fast(64, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(64, 1024, 128, 2)   # 256 row tiles: small launch
     assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 0) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2) + 32 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 128 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(300, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(300, 4096, 128, 1) + 100 * 4096 * 4096 * 2   # 3 x 100, not 128 + 128 + 44
