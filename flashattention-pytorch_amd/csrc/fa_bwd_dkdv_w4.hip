@@ -111,9 +111,11 @@ template <int OFF> __device__ __forceinline__ void lds_acc_init_asm(unsigned add
 // ABL != 0: profiling ablations (wrong results on purpose; option dkdv_abl):
 //   bit 0: no vector slices (P, dS)   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no LDS operand requests
 //   bit 3: no row-constant loads      bit 4: no address updates
-//   bit 6: (DS variant) no dS stores
 //   bit 5: shader-clock stamps around the block loop; wave 0 of workgroup 0 overwrites dk[0..7] with
-//          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py)
+//          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py), and every wave of workgroup 0 leaves its stamps of
+//          blocks 0 .. 23 — own stream done / behind the barrier — in dk[32 + 64 w ..] (tools/ds_store_cycles.py)
+//   bit 6: (DS variant) no dS stores    bit 7: round 2's tile waits (one tile earlier than needed)
+//   option value + 512: one key tile per workgroup under the mask too;  bit 11: no mask branch in the loop
 // LDS-DMA pieces of the stream: the LDS address and the soffset come from scalar arithmetic on kernel arguments and the
 // block counter (no v_readfirstlane feeds them), so the one wait state M0 needs is all the padding there is
 // (fa_common.h's dma16_issue carries the five states a VALU-written SGPR operand would need).
@@ -299,10 +301,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     // the real ones; not waiting for them saves nothing; in the nearly empty gaps of the dP' chains they cost the same:
     // profiles/r02_ds_handover.md) — about a third of it in cycles, the rest in clock: the chip is power-limited.
     auto wait_tiles = [&](bool first_block = false) {
-        if (!DS || (ABL & 64)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (ABL & 128) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");   // experiment: only the tile the next block reads
-        else if (first_block) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        if (ABL & 128) {   // round 2's counts: the tile TWO blocks ahead has landed (one block of slack more than needed)
+            if (!DS || (ABL & 64)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (first_block) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        } else if (!DS || (ABL & 64)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // this block's and the previous block's pieces may be in flight
+        else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");                            // ... and the stores of this and the two blocks before
     };
     const int ds_voff = 32 * (lane & 31) + 16 * (lane >> 5);
     unsigned long long dsp = 0;                  // DS: this wave's two dS tiles of the current block (wave-uniform address)
@@ -371,7 +375,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
             }
         }
     };
-    unsigned long long tq[8] = {};
     auto block = [&](int blk) {
         const int dlt = ((blk + 1) & (NBUF - 1)) ? BUF : -(NBUF - 1) * BUF;   // to the next tile's buffer
         // Vector work, cut into single instructions' worth and placed by the table above (w4sched::kSched): MUL + EXP: one
@@ -404,7 +407,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
         };
         auto slice = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr ((ABL & 8192) != 0 && (S % 8) == 7) asm volatile("s_memtime %0" : "=s"(tq[S / 8]));   // experiment: eight stamps inside the block
             if constexpr (DS && !(ABL & 64) && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});
             {   // ABL bits: see the kernel's header comment
                 for_each_const([&](auto jc) {
@@ -569,14 +571,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
     for (int blk = 0;; ++blk) {
         const bool last = blk >= nfeed - 1;   // (also when there is no feed-only block)
         if (blk < nfeed) stage(blk + 3);
-        if ((ABL & 4096) && last && blk < nfeed && fb < nblk) {   // experiment: matrix pipe warm-up ahead of the wave's first block
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                W4Stream<Tag, false>::v(vf[0][i & 7], vf[1][i & 7], sacc[0]);
-                W4Stream<Tag, false>::v(vf[1][i & 7], vf[0][i & 7], sacc[1]);
-            }
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc[0]), "+v"(sacc[1]));
-        }
         if (last && fb < nblk) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing older may sit in the LDS queue: the counts are exact
             lds_acc_init<0>(laddr, sacc[0]);
@@ -601,22 +595,13 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
 #pragma unroll 1
         for (int blk = fb; blk < nblk; ++blk) {
             block(blk);
-            if ((ABL & 8192) && L == 0 && blk < 8) {   // the in-block stamps of blocks 0 .. 7: dk[320 + 64 w + 8 blk + i]
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 8) {
-                    unsigned long long tv = tq[0];
-#pragma unroll
-                    for (int i = 1; i < 8; ++i) tv = lane == i ? tq[i] : tv;
-                    reinterpret_cast<unsigned*>(dk)[320 + 64 * w + 8 * blk + lane] = (unsigned)tv;
-                }
-            }
             if ((ABL & 32) && L == 0 && blk < 24) {   // per-wave stamps of blocks 0 .. 23 of workgroup 0's last tile: own work done, dk[32 + 64 w + 2 blk]
                 unsigned long long t_now;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");
                 if (lane == 0) reinterpret_cast<unsigned*>(dk)[32 + 64 * w + 2 * blk] = (unsigned)t_now;
             }
             if (!(ABL & 2048)) mask_init(blk + 1);   // on the next block's initial accumulators, outside the stream (the only branch)
-            if (DS && !(ABL & 1024)) dsp += (unsigned long long)nkb32 * 2048;   // (1024: experiment — every block's stores land on the same 4 KiB)
+            if (DS) dsp += (unsigned long long)nkb32 * 2048;
             if (!(ABL & 2)) {
                 wait_tiles(blk == fb);
                 __builtin_amdgcn_s_barrier();
@@ -640,8 +625,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                  : "+a"(dka[0][0]), "+a"(dka[0][1]), "+a"(dka[0][2]), "+a"(dka[0][3]), "+a"(dka[1][0]), "+a"(dka[1][1]),
                    "+a"(dka[1][2]), "+a"(dka[1][3]), "+a"(dva[0][0]), "+a"(dva[0][1]), "+a"(dva[0][2]), "+a"(dva[0][3]),
                    "+a"(dva[1][0]), "+a"(dva[1][1]), "+a"(dva[1][2]), "+a"(dva[1][3]));
-    if (DS && (ABL & 256)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // experiment: the last block's dS stores may stay in flight
-    else
     dma_wait_all();   // nothing of this workgroup may still be writing LDS when the next one takes the CU
     // a wave only ever read its own 64 K rows: that slice of the K tile is its staging area for whole-row stores
     char* stg = Ks + w * 64 * D * 2;
@@ -707,21 +690,10 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
         if constexpr (std::is_same<Tag, bf16_tag>::value) switch (option(OPT_DKDV_ABL)) {
             case 64: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 64, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 64, 1, true, 3>);
             case 128: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 128, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 128, 1, true, 3>);
-            case 256: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 256, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 256, 1, true, 3>);
-            case 384: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 384, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 384, 1, true, 3>);
-            case 1024: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 1024, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 1024, 1, true, 3>);
             case 32: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 32, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 32, 1, true, 3>);
             case 96: return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 96, 2, true, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 96, 1, true, 3>);
             case 544: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 32, 1, true, 3>); break;
             case 608: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 96, 1, true, 3>); break;
-            case 4192: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 4192, 2, true, 3>); break;   // stamps, no stores, warm-up
-            case 4096: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 4096, 2, true, 3>); break;
-            case 97: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 97, 2, true, 3>); break;
-            case 100: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 100, 2, true, 3>); break;
-            case 104: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 104, 2, true, 3>); break;
-            case 112: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 112, 2, true, 3>); break;
-            case 125: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 125, 2, true, 3>); break;
-            case 8317: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 8317, 2, true, 3>); break;
             case 2080: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 2080, 2, true, 3>); break;   // stamps, no mask branch in the loop
             case 512: if (a.causal) return launch(bwd_dkdv_w4_kernel<Tag, true, 0, 1, true, 3>); break;
             default: break;
@@ -743,6 +715,7 @@ static hipError_t launch_dkdv_w4_t(const BwdArgs& a, const float* nlse, const fl
         }
     }
     if constexpr (std::is_same<Tag, bf16_tag>::value) {
+        if (option(OPT_DKDV_ABL) == 128) return a.causal ? launch(bwd_dkdv_w4_kernel<Tag, true, 128, 2, false, 3>) : launch(bwd_dkdv_w4_kernel<Tag, false, 128, 1, false, 3>);
         if (!a.causal) switch (option(OPT_DKDV_ABL)) {   // profiling ablations: see the kernel's header comment
             case 1: return launch(bwd_dkdv_w4_kernel<Tag, false, 1>);
             case 2: return launch(bwd_dkdv_w4_kernel<Tag, false, 2>);
