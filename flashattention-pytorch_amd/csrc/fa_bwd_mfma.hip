@@ -377,14 +377,15 @@ static bool bwd_ds_path(int dtype, int64_t d, int64_t bh, int64_t n, bool causal
     if (dq_opt == 6 ? (dkdv_opt != 0 && dkdv_opt != 5) : (dq_opt != 0 || dkdv_opt != 0)) return false;
     if (option(OPT_DQ_KT) || option(OPT_DQ_TPW) || option(OPT_DQ_NLF) || (option(OPT_DQ_W4) && option(OPT_DQ_W4) != 3) || option(OPT_DKDV_TPW) || (option(OPT_DKDV_ABL) && option(OPT_DKDV_ABL) < 32) || option(OPT_DQ_ABL)) return false;
     if (ds_workspace_bytes(1, n, nk > 0 ? nk : n) > ds_chunk_bytes()) return false;   // one (b,h) alone is over the chunk size
-    // Up to 256 tiles of 256 rows the recomputing stream kernels are 2 - 3 % ahead (profiles/r02_ds_handover.md).
     if (dq_opt == 6) return true;
-    if (small_grid(bh, n, true)) return false;
-    // Under the causal mask too (round 3, profiles/r03_causal_handover.md: the dQ product kernel pairs its query tiles, the
-    // dK/dV kernel's diagonal blocks no longer wait for late starters): 2 - 25 % ahead of the recomputing pass from 512 row tiles
-    // on — the short rows most, 2048 x 256: 0.37 against 0.49 ms — while a chunk holds 16 (b,h) units or the whole launch; below
-    // that its launches do not fill the chip (N = 16384: 8 units per chunk, -1 %).
-    if (causal) return ds_chunk_units(bh, n, nk) >= (bh < 16 ? bh : 16);
+    if (option(OPT_SMALL_GRID) == 2) return false;   // (sweeps: the small-launch kernels forced)
+    // Without the mask the hand-over is ahead at every launch size (round 3, profiles/r03_bwd_variants.md: 12 - 17 % on launches of
+    // 16 - 96 row tiles — a recomputing dQ workgroup walks all the keys, the product kernel's stages are short —, 5 - 9 % at the
+    // headline size; round 2 had the recomputing kernels 2 - 3 % ahead up to 256 tiles: the stream kernel's start of a tile was
+    // 2 500 cycles longer then).  Under the causal mask: rows of 4096 and more always (4 - 9 %), shorter rows from 160 row tiles
+    // on (below, the 8-wave / 4-wave dK/dV kernels with 128-key tiles serve the launch better: 64 x 512: 0.063 against 0.079 ms),
+    // and while a chunk holds 16 (b,h) units or the whole launch (N = 16384 x 32 units: 8 per chunk, -1 %).
+    if (causal) return (n >= 4096 || bh * ((n + 255) / 256) >= 160) && ds_chunk_units(bh, n, nk) >= (bh < 16 ? bh : 16);
     return true;
 }
 size_t bwd_mfma_workspace_bytes(int64_t bh, int64_t n, int64_t d, bool atomic_variant) {

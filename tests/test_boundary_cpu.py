@@ -58,7 +58,8 @@ def test_workspace_query_and_argument_validation_without_gpu():
     assert lib.fa_backward_workspace_bytes_fast(32, 16384, 128, 2, 1) == lib.fa_backward_workspace_bytes(32, 16384, 128, 2)    # 8 units per chunk: O(BH N) bytes
     assert lib.fa_backward_workspace_bytes_fast(8, 16384, 128, 2, 1) == lib.fa_backward_workspace_bytes(8, 16384, 128, 2) + 8 * 16384 * 16384 * 2
     assert lib.fa_backward_workspace_bytes_fast(512, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(512, 1024, 128, 2) + 512 * 1024 * 1024 * 2   # short rows too
-    assert lib.fa_backward_workspace_bytes_fast(64, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(64, 1024, 128, 2)   # 256 row tiles: small launch
+    assert lib.fa_backward_workspace_bytes_fast(32, 1024, 128, 2, 1) == lib.fa_backward_workspace_bytes(32, 1024, 128, 2)   # short rows, < 160 row tiles: the small-launch kernels
+    assert lib.fa_backward_workspace_bytes_fast(2, 4096, 128, 2, 1) == lib.fa_backward_workspace_bytes(2, 4096, 128, 2) + 2 * 4096 * 4096 * 2   # rows of 4096: always
     assert lib.fa_backward_workspace_bytes_fast(32, 4096, 128, 2, 0) == lib.fa_backward_workspace_bytes(32, 4096, 128, 2) + 32 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(2048, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(2048, 4096, 128, 1) + 128 * 4096 * 4096 * 2
     assert lib.fa_backward_workspace_bytes_fast(300, 4096, 128, 1, 0) == lib.fa_backward_workspace_bytes(300, 4096, 128, 1) + 100 * 4096 * 4096 * 2   # 3 x 100, not 128 + 128 + 44
@@ -67,8 +68,7 @@ def test_workspace_query_and_argument_validation_without_gpu():
     for bh_, n_ in ((1, 4096), (256, 4096), (4096, 4096), (100, 16384), (7, 40000), (3, 100000)):    # bounded whatever BH and N are
         assert lib.fa_backward_workspace_bytes_fast(bh_, n_, 128, 2, 0) - lib.fa_backward_workspace_bytes(bh_, n_, 128, 2) <= 4 << 30
     assert lib.fa_backward_workspace_bytes_fast(80, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(80, 1000, 128, 2) + 80 * 32 * 32 * 2048  # ragged N: whole tiles
-    assert lib.fa_backward_workspace_bytes_fast(64, 1000, 128, 2, 0) == lib.fa_backward_workspace_bytes(64, 1000, 128, 2)  # 256 tiles of 256 rows: still the recomputing pass
-    assert lib.fa_backward_workspace_bytes_fast(2, 512, 128, 2, 0) == lib.fa_backward_workspace_bytes(2, 512, 128, 2)     # small launch
+    assert lib.fa_backward_workspace_bytes_fast(2, 512, 128, 2, 0) == lib.fa_backward_workspace_bytes(2, 512, 128, 2) + 2 * 16 * 16 * 2048   # small launches too (round 3)
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 64, 2, 0) == lib.fa_backward_workspace_bytes(256, 4096, 64, 2)  # d = 64
     assert lib.fa_backward_workspace_bytes_fast(256, 4096, 128, 0, 0) == lib.fa_backward_workspace_bytes(256, 4096, 128, 0)  # fp32
     # validation happens before any HIP call: bad dtype / head_dim > 256 / null pointers

@@ -783,7 +783,7 @@ def test_many_small_heads(device):
 
 
 # ---- the dS hand-over backward (csrc/fa_bwd_dq_ds.hip): dK/dV kernel stores dS, dQ = scale * dS K ----
-DS_SHAPES = [(2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
+DS_SHAPES = [(4, 40), (2, 130), (2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
 
 
 @pytest.mark.parametrize("bh,n", DS_SHAPES)
@@ -791,7 +791,7 @@ DS_SHAPES = [(2, 256), (3, 300), (3, 1000), (2, 2048 + 40), (1, 4096)]
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("rows", [512, 256])
 def test_ds_handover_backward_matches_oracle(bh, n, causal, dtype, rows, device):
-    """Option dq = 6 forces the path on launches of any size (its default is launches of > 256 row tiles); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
+    """Option dq = 6 forces the path on launches of any size (round 3: it is the default without the mask at every size, under it from 160 row tiles or rows of 4096 on); ragged N, the diagonal's unwritten blocks, several key tiles; from N = 1000 on one (b,h) unit per chunk
     (ds_chunk_mb), so the chunk loop runs too."""
     import flashattention_lab_cuda as ext
 

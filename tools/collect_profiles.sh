@@ -31,6 +31,9 @@ python3 tools/bench_fp8.py > "$OUT/fp8_forward_config5.json" 2> "$OUT/fp8.err"
 cp benchmarks/results/*"$R"*.json "$OUT/" 2>/dev/null
 python3 tools/w4_cycles.py --kernel dkdv > "$OUT/cycles_dkdv.md" 2>/dev/null
 python3 tools/w4_cycles.py --kernel dq > "$OUT/cycles_dq.md" 2>/dev/null
+python3 tools/ds_store_cycles.py > "$OUT/diag_cycles.md" 2>/dev/null
+python3 tools/bwd_variant_sweep.py --causal > "$OUT/bwd_variants_causal.md" 2>/dev/null
+python3 tools/bwd_variant_sweep.py > "$OUT/bwd_variants.md" 2>/dev/null
 python3 tools/collect_traffic.py "$OUT/traffic.json" $(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1) $(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1) > /dev/null 2>> "$OUT/bench.err"
 python3 tools/pmc_summary.py $(find "$OUT/pmc_sq" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_sq_counters.txt" 2>> "$OUT/bench.err"
 cp $(find "$OUT/ks" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
