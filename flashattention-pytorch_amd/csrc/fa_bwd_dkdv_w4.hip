@@ -112,7 +112,7 @@ template <int OFF> __device__ __forceinline__ void lds_acc_init_asm(unsigned add
 //   bit 0: no vector slices (P, dS)   bit 1: no LDS-DMA in the stream, no tile wait, no barrier   bit 2: no LDS operand requests
 //   bit 3: no row-constant loads      bit 4: no address updates
 //   bit 5: shader-clock stamps around the block loop; wave 0 of workgroup 0 overwrites dk[0..7] with
-//          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py), and every wave of workgroup 0 leaves its stamps of
+//          (cycles of the loop, blocks) as two uint32 (tools/w4_cycles.py), and (DS variant) every wave of workgroup 0 leaves its stamps of
 //          blocks 0 .. 23 — own stream done / behind the barrier — in dk[32 + 64 w ..] (tools/ds_store_cycles.py)
 //   bit 6: (DS variant) no dS stores    bit 7: round 2's tile waits (one tile earlier than needed)
 //   option value + 512: one key tile per workgroup under the mask too;  bit 11: no mask branch in the loop
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
 #pragma unroll 1
         for (int blk = fb; blk < nblk; ++blk) {
             block(blk);
-            if ((ABL & 32) && L == 0 && blk < 24) {   // per-wave stamps of blocks 0 .. 23 of workgroup 0's last tile: own work done, dk[32 + 64 w + 2 blk]
+            if (DS && (ABL & 32) && L == 0 && blk < 24) {   // per-wave stamps of blocks 0 .. 23 of workgroup 0's last tile: own work done, dk[32 + 64 w + 2 blk]
                 unsigned long long t_now;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");
                 if (lane == 0) reinterpret_cast<unsigned*>(dk)[32 + 64 * w + 2 * blk] = (unsigned)t_now;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_w4_kernel(const uint16_t* __r
                 wait_tiles(blk == fb);
                 __builtin_amdgcn_s_barrier();
             }
-            if ((ABL & 32) && L == 0 && blk < 24) {   // ... and behind the barrier: dk[32 + 64 w + 2 blk + 1]
+            if (DS && (ABL & 32) && L == 0 && blk < 24) {   // ... and behind the barrier: dk[32 + 64 w + 2 blk + 1]
                 unsigned long long t_now;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");
                 if (lane == 0) reinterpret_cast<unsigned*>(dk)[32 + 64 * w + 2 * blk + 1] = (unsigned)t_now;
