@@ -132,8 +132,8 @@ int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, c
 
 size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype);
 /* The size with which a call WITHOUT mask, block-sparse mask and dropout (extras = 0) hands dS from its dK/dV kernel to its dQ
- * kernel, as fa_backward_workspace_bytes_fast does for the square backward (d = 128, 16-bit tensors, no causal mask, large
- * launches; Nq != Nk included; at most 4 GiB more).  Equals fa_ex_backward_workspace_bytes where that does not apply. */
+ * kernel, as fa_backward_workspace_bytes_fast does for the square backward (d = 128, 16-bit tensors; Nq != Nk only without the causal
+ * mask; at most 4 GiB more).  Equals fa_ex_backward_workspace_bytes where that does not apply. */
 size_t fa_ex_backward_workspace_bytes_fast(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype, int causal, int extras);
 
 /* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */
@@ -141,12 +141,12 @@ size_t fa_ex_backward_workspace_bytes_fast(int64_t bh, int64_t nq, int64_t nk, i
  * FA_MODE_BWD_ATOMIC only); ask again after changing the mode */
 size_t fa_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype);
 /* The size that lets the backward hand dS from its dK/dV kernel to its dQ kernel instead of recomputing S and dP there
- * (d = 128, 16-bit tensors, no causal mask, launches of > 256 row tiles: N * N * 2 bytes per (b,h), at most 4 GiB whatever BH
- * and N are — the (b,h) units are worked through in equal chunks of that size; option ds_chunk_mb moves the bound).  Equals
- * fa_backward_workspace_bytes where that does not apply: under the causal mask the recomputing backward, which needs O(BH N)
- * bytes only, is as fast (option dq = 6 forces the hand-over there too).  A backward call given less than this (but at least
- * fa_backward_workspace_bytes) runs the recomputing dQ pass: same results up to summation order, about 3 % more time for
- * forward + backward at 256 x 4096 x 128 (profiles/r03_ds_chunk_sweep.md). */
+ * (d = 128, 16-bit tensors: N * N * 2 bytes per (b,h), at most 4 GiB whatever BH and N are — the (b,h) units are worked through
+ * in equal chunks of that size; option ds_chunk_mb moves the bound).  Without the causal mask that serves every launch; under it
+ * rows of 4096 and more, or launches of 160 and more 256-row tiles, while a chunk holds 16 units or the whole launch (option
+ * dq = 6 forces it elsewhere).  Equals fa_backward_workspace_bytes where it does not apply.  A backward call given less than this
+ * (but at least fa_backward_workspace_bytes) runs the recomputing dQ pass: same results up to summation order, 4 - 17 % more
+ * backward time depending on the launch (profiles/r03_bwd_variants.md, r03_ds_chunk_sweep.md). */
 size_t fa_backward_workspace_bytes_fast(int64_t bh, int64_t n, int64_t d, int dtype, int causal);
 size_t fa3_forward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8);

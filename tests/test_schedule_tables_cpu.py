@@ -60,7 +60,7 @@ def test_dkdv_ds_variant_adds_only_its_four_stores():
     for s_, (a, b) in enumerate(zip(_ops(rows), _ops(ds_rows))):
         assert b == a + ([stores[s_]] if s_ in stores else []), (s_, a, b)
     src = open(os.path.join(CSRC, "fa_bwd_dkdv_w4.hip")).read()
-    assert "if constexpr (DS && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});" in src
+    assert "if constexpr (DS && !(ABL & 64) && S >= 52 && S < 56) DSST(integral_constant<int, ((S - 52) / 2)>{}, integral_constant<int, ((S - 52) % 2)>{});" in src
 
 
 def test_dq_table_is_the_generators_output_and_within_budget():
