@@ -80,7 +80,7 @@ struct LiveScan {
 
 struct MaskSrc {
     buf_rsrc_t rs;
-    bool on, dwords;
+    bool on, dwords, quads;
 };
 __device__ __forceinline__ MaskSrc make_mask_src(const ExParams& p, int bh) {
     MaskSrc m;
@@ -88,6 +88,7 @@ __device__ __forceinline__ MaskSrc make_mask_src(const ExParams& p, int bh) {
     const uint8_t* base = m.on ? p.mask + (size_t)bh * p.mask_bh : nullptr;
     m.rs = make_rsrc(base, m.on ? (unsigned)p.nq * (unsigned)p.nk : 0u);
     m.dwords = m.on && (p.nk & 3) == 0 && (p.mask_bh & 3) == 0 && (((uintptr_t)p.mask) & 3) == 0;
+    m.quads = m.on && (p.nk & 15) == 0 && (p.mask_bh & 15) == 0 && (((uintptr_t)p.mask) & 15) == 0;
     return m;
 }
 __device__ __forceinline__ unsigned mask_load_b32(const MaskSrc& m, int off) { return __builtin_amdgcn_raw_buffer_load_b32(m.rs, off, 0, 0); }
@@ -98,6 +99,17 @@ __device__ __forceinline__ unsigned mask_load_b8(const MaskSrc& m, int off) { re
 __device__ __forceinline__ void mask_words_q(const MaskSrc& m, int row, int nk, int kcol, unsigned (&wd)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) wd[g] = mask_load_b32(m, row * nk + kcol + 8 * g);
+}
+// The same words from ONE 16-byte load per lane (round 3; Nk, pointer and (b,h) stride multiples of 16): the two lanes of a row
+// (r, h = 0 / 1) fetch bytes 16 h .. 16 h + 15 of the row's 32 and trade the dwords the other one's registers stand for — lane
+// (r, 0) holds keys 0-3, 8-11, 16-19, 24-27 of the block, lane (r, 1) keys 4-7, 12-15, 20-23, 28-31 — with two
+// v_permlane32_swap (upper half of the first operand <-> lower half of the second).  A quarter of the load instructions, the
+// same cache lines: the address unit walks 64 lanes per instruction either way.
+__device__ __forceinline__ void mask_words_q16(const MaskSrc& m, int row, int nk, int kblk, int h, unsigned (&wd)[4]) {
+    const u32x4 w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(m.rs, row * nk + kblk + 16 * h, 0, 0));
+    const auto s01 = __builtin_amdgcn_permlane32_swap(w[0], w[1], false, false);   // [0]: lo own w0 | hi <- lo's w1;  [1]: lo <- hi's w0 | hi own w1
+    const auto s23 = __builtin_amdgcn_permlane32_swap(w[2], w[3], false, false);
+    wd[0] = s01[0]; wd[1] = s23[0]; wd[2] = s01[1]; wd[3] = s23[1];
 }
 __device__ __forceinline__ unsigned bits_of_words(const unsigned (&wd)[4]) {
     // Structured masks (a causal or windowed mask handed over as a dense one) are all-visible or all-masked over most
@@ -124,7 +136,12 @@ __device__ __forceinline__ float keep_or_minus_inf(float s, unsigned vis, int i)
     const int m = ((int)(vis << (31 - i))) >> 31;                     // v_bfe_i32: 0 or -1
     return __uint_as_float((__float_as_uint(s) & (unsigned)m) | (0xff800000u & ~(unsigned)m));   // v_bfi_b32
 }
-__device__ __forceinline__ unsigned dense_bits_q(const MaskSrc& m, int row, int nk, int kcol) {
+__device__ __forceinline__ unsigned dense_bits_q(const MaskSrc& m, int row, int nk, int kcol /* block's first key + 4 h */, int h) {
+    if (m.quads) {
+        unsigned wd[4];
+        mask_words_q16(m, row, nk, kcol - 4 * h, h, wd);
+        return bits_of_words(wd);
+    }
     if (m.dwords) {
         unsigned wd[4];
         mask_words_q(m, row, nk, kcol, wd);
@@ -140,6 +157,32 @@ __device__ __forceinline__ unsigned dense_bits_k(const MaskSrc& m, int rrow, int
     unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bits |= mask_load_b8(m, (rrow + rc_of(i)) * nk + key) ? (1u << i) : 0u;
+    return bits;
+}
+
+// The same through LDS (round 3; Nk, pointer and (b,h) stride multiples of 16): the block's 32 x 32 mask bytes are exactly one
+// 16-byte load per lane (lane l: row l >> 1, bytes 16 (l & 1) ..), written to a 1 KiB image [row][32 bytes] of the wave's own,
+// from which the lane reads its key's column — 16 byte reads from LDS instead of 16 byte loads from memory.  Structured masks
+// leave on the words as loaded: all bytes set / all bytes clear over the wave are decided before the round trip.  A wave's
+// LDS instructions execute in order, so the reads see the wave's own writes without a barrier.
+__device__ __forceinline__ unsigned dense_bits_k_lds(const MaskSrc& m, int rb0, int nk, int kw0, int lane, char* img /* this wave's 1 KiB */) {
+    asm volatile("" : "+v"(lane));   // the lane-constant addresses below are made per call: hoisted, they are three registers this kernel does not have
+    const u32x4 w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(m.rs, (rb0 + (lane >> 1)) * nk + kw0 + 16 * (lane & 1), 0, 0));
+    unsigned zero_byte = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zero_byte |= (w[g] - 0x01010101u) & ~w[g] & 0x80808080u;
+    if (__all(zero_byte == 0)) return 0xffffu;
+    if (__all((w[0] | w[1] | w[2] | w[3]) == 0)) return 0u;
+    *reinterpret_cast<u32x4*>(img + 16 * lane) = w;
+    const int c = lane & 31, h = lane >> 5;
+    unsigned bits = 0;
+    const char* col = img + 128 * h + c;   // row 4 h + rc(i), rc(i) = (i & 3) + 8 (i >> 2): immediate offsets from one address
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits |= (*reinterpret_cast<const volatile uint8_t*>(col + 32 * (j + 8 * g)) ? 1u : 0u) << (4 * g + j);
+        asm volatile("" : "+v"(bits));   // four reads in flight at a time: the kernel has no registers to spare
+    }
     return bits;
 }
 
@@ -252,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void exm_fwd_kernel(const uint16_t* __restr
                 vis[kb] = 0xffffu;
                 kp[kb] = 0xffffu;
                 if constexpr (FEAT & kFeatMask) {
-                    if (msk.on) vis[kb] = dense_bits_q(msk, qrow, nk, k0 + 32 * kb + 4 * h);
+                    if (msk.on) vis[kb] = dense_bits_q(msk, qrow, nk, k0 + 32 * kb + 4 * h, h);
                     if (use_bm && p.bmask[rbw * p.nbc + min(k0 + 32 * kb, nk - 1) / p.bc] == 0) vis[kb] = 0;
                 }
                 if constexpr (FEAT & kFeatDrop) {
@@ -413,7 +456,9 @@ __global__ __launch_bounds__(256) void exm_prep_kernel(const uint16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ dK / dV
-template <typename Tag, int D, int FEAT>
+// M16: the dense mask (if any) is 16-byte aligned in every respect — its bytes come through the wave's LDS image
+// (dense_bits_k_lds); a separate instantiation, not a run-time choice: with both loaders in one kernel the masked form spills
+template <typename Tag, int D, int FEAT, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void exm_dkdv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, const uint16_t* __restrict__ dout,
                                                           const float* __restrict__ nlse, const float* __restrict__ ndelta,
@@ -500,7 +545,8 @@ __global__ __launch_bounds__(512, 2) void exm_dkdv_kernel(const uint16_t* __rest
             const int rb0 = qs + 32 * qb;              // first row of the block; register i holds row rb0 + 4 h + rc(i)
             unsigned vis = 0xffffu, kp = 0xffffu;
             if constexpr (FEAT & kFeatMask) {
-                if (msk.on) vis = dense_bits_k(msk, rb0 + 4 * h, nk, key);
+                if constexpr (M16) { if (msk.on) vis = dense_bits_k_lds(msk, rb0, nk, kw0, lane, reinterpret_cast<char*>(Ls + 2 * 128) + 1024 * w); }
+                else if (msk.on) vis = dense_bits_k(msk, rb0 + 4 * h, nk, key);
                 if (use_bm && p.bmask[(min(rb0, nq - 1) / p.br) * p.nbc + cbw] == 0) vis = 0;
             }
             if constexpr (FEAT & kFeatDrop) {
@@ -699,8 +745,8 @@ __global__ __launch_bounds__(512, 2) void exm_dq_kernel(const uint16_t* __restri
         unsigned visw[2] = {0xffffu, 0xffffu};
         if constexpr (FEAT & kFeatMask) {
             if (msk.on) {
-                visw[0] = dense_bits_q(msk, qrow, nk, k0 + 4 * h);
-                visw[1] = dense_bits_q(msk, qrow, nk, k0 + 32 + 4 * h);
+                visw[0] = dense_bits_q(msk, qrow, nk, k0 + 4 * h, h);
+                visw[1] = dense_bits_q(msk, qrow, nk, k0 + 32 + 4 * h, h);
                 if (tn < ntiles) stage(cur ^ 1, tn * BN);
             }
 #pragma unroll
@@ -835,8 +881,9 @@ static hipError_t exm_bwd_t(const ExArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.nk > 0) {
-        const size_t smem = (size_t)256 * D * 2 + 4 * 64 * D * 2 + 2 * 128 * sizeof(float);
-        auto kern = exm_dkdv_kernel<Tag, D, FEAT>;
+        const bool m16 = (FEAT & kFeatMask) && p.mask != nullptr && (p.nk & 15) == 0 && (p.mask_bh & 15) == 0 && (((uintptr_t)p.mask) & 15) == 0;
+        const size_t smem = (size_t)256 * D * 2 + 4 * 64 * D * 2 + 2 * 128 * sizeof(float) + (m16 ? 8 * 1024 : 0);   // + the waves' mask images
+        auto kern = m16 ? exm_dkdv_kernel<Tag, D, FEAT, (FEAT & kFeatMask) != 0> : exm_dkdv_kernel<Tag, D, FEAT, false>;
         e = ensure_dynamic_smem(reinterpret_cast<const void*>(kern), (int)smem);
         if (e != hipSuccess) return e;
         dim3 grid((unsigned)(((a.nk + 255) / 256) * a.bh));
