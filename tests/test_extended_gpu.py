@@ -94,6 +94,8 @@ BIG_CASES = [
     (2, 900, 700, 128, True, None, None, 0.0, 0.6),          # Nq > Nk: the first 200 rows see nothing
     (1, 600, 1000, 128, False, "shared", None, 0.0, 0.5),    # Nk % 4 == 0: dword mask loads
     (2, 513, 777, 64, False, "per_bh", None, 0.0, 0.5),      # byte mask loads
+    (2, 600, 1040, 128, False, "per_bh", None, 0.0, 0.5),    # Nk % 16 == 0: one 16-byte mask load per lane and block (half-wave swap / LDS image)
+    (2, 513, 784, 64, True, "per_bh", None, 0.0, 0.7),       # the same at d = 64, under the causal flag too
     (1, 1024, 1024, 128, True, None, (128, 128), 0.0, 0.3),  # most tiles dead
     (1, 800, 1100, 64, False, None, (64, 32), 0.0, 0.2),
     (2, 520, 640, 128, True, "shared", (32, 32), 0.2, 0.7),  # everything at once
