@@ -409,8 +409,8 @@ size_t fa_ex_backward_workspace_bytes_fast(int64_t bh, int64_t nq, int64_t nk, i
     if (extras || bh <= 0 || nq <= 0 || nk <= 0 || g_mode.load() == FA_MODE_F32_GENERIC || fa::option(fa::OPT_EX_PATH) == 1 || fa::option(fa::OPT_EX_PATH) == 3) return need;
     if (!fa::bwd_mfma_supported(dtype, d)) return need;
     if (nq == nk) return need + fa::bwd_ds_extra_bytes(bh, nq, d, dtype, causal != 0, bwd_atomic_variant());   // the plain backward's own rule
-    if (causal || !fa::nqnk_mfma_supported(dtype, d, bh, nq, nk, 0)) return need;
-    return need + fa::bwd_ds_extra_bytes(bh, nq, d, dtype, false, false, nk);
+    if (!fa::nqnk_mfma_supported(dtype, d, bh, nq, nk, causal)) return need;   // (under the mask: Nk >= Nq)
+    return need + fa::bwd_ds_extra_bytes(bh, nq, d, dtype, causal != 0, false, nk);
 }
 
 size_t fa3_backward_workspace_bytes(int64_t bh, int64_t n, int64_t d, int dtype, int fp8) {

@@ -452,10 +452,10 @@ hipError_t launch_ex(const ExArgs& a, bool backward, hipStream_t st) {
         b.nk = a.nk;
         float* nlse = reinterpret_cast<float*>(a.workspace);
         float* ndelta = nlse + (size_t)a.bh * a.nq;
-        // no mask: with room for the dS tiles behind the row constants the dK/dV kernel hands dS to the dQ product kernel
-        // (DESIGN.md 4c), as the square backward does
+        // with room for the dS tiles behind the row constants the dK/dV kernel hands dS to the dQ product kernel,
+        // as the square backward does and by its rule — since round 3 also under the (shifted) causal diagonal
         const size_t base = (ex_backward_workspace_bytes(a.bh, a.nq) + 255) & ~(size_t)255;
-        const size_t extra = a.causal ? 0 : bwd_ds_extra_bytes(a.bh, a.nq, a.d, a.dtype, false, false, a.nk);
+        const size_t extra = bwd_ds_extra_bytes(a.bh, a.nq, a.d, a.dtype, a.causal != 0, false, a.nk);
         if (extra && a.workspace_bytes >= base + extra)
             return launch_bwd_handover(b, nlse, ndelta, reinterpret_cast<char*>(a.workspace) + base, st);
         hipError_t e = launch_bwd_dq_w4(b, nlse, ndelta, st);   // makes the row constants on its way

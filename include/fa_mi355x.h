@@ -132,8 +132,8 @@ int fa_ex_backward(const void* q, const void* k, const void* v, const void* o, c
 
 size_t fa_ex_backward_workspace_bytes(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype);
 /* The size with which a call WITHOUT mask, block-sparse mask and dropout (extras = 0) hands dS from its dK/dV kernel to its dQ
- * kernel, as fa_backward_workspace_bytes_fast does for the square backward (d = 128, 16-bit tensors; Nq != Nk only without the causal
- * mask; at most 4 GiB more).  Equals fa_ex_backward_workspace_bytes where that does not apply. */
+ * kernel, as fa_backward_workspace_bytes_fast does for the square backward and by the same rule (d = 128, 16-bit tensors; Nq != Nk
+ * included, under the causal mask with Nk >= Nq; at most 4 GiB more).  Equals fa_ex_backward_workspace_bytes where that does not apply. */
 size_t fa_ex_backward_workspace_bytes_fast(int64_t bh, int64_t nq, int64_t nk, int64_t d, int dtype, int causal, int extras);
 
 /* --- support entry points (no reference counterpart: the reference allocates inside the callee) --- */

@@ -325,11 +325,12 @@ def test_broadcast_masks_through_the_wrapper(shape, device):
     torch.testing.assert_close(o.cpu().float().reshape(b * h, nq, d), ro.float(), rtol=5e-2, atol=5e-2)
 
 
-@pytest.mark.parametrize("nq,nk", [(1024, 1536), (1100, 1300), (1536, 1024), (1024, 1024)])
-def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
+@pytest.mark.parametrize("nq,nk,causal", [(1024, 1536, False), (1100, 1300, False), (1536, 1024, False), (1024, 1024, False),
+                                          (1024, 1536, True), (1100, 1300, True), (1024, 1024, True)])
+def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, causal, device):
     """`fa_ex_backward` without mask and dropout on a launch big enough for it (> 256 row tiles, no causal mask)
     takes the dS hand-over — preparation launch, dK/dV kernel with dS stores, dQ product — also with Nq != Nk (round 2: those
-    calls recomputed): the library profile shows the preparation launch, the workspace is fa_ex_backward_workspace_bytes_fast's,
+    calls recomputed; round 3: under the shifted causal diagonal too, Nk >= Nq): the library profile shows the preparation launch, the workspace is fa_ex_backward_workspace_bytes_fast's,
     the gradients agree with the recomputing pass (option dq = 5) and with the fp64 oracle."""
     import flashattention_lab_cuda as ext
 
@@ -343,16 +344,16 @@ def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
     scale = d ** -0.5
     lib = ext._lib
     small = int(lib.fa_ex_backward_workspace_bytes(bh, nq, nk, d, 2))
-    fast = int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 0, 0))
+    fast = int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, int(causal), 0))
     tiles = ((nq + 31) // 32) * (8 * ((nk + 255) // 256))
     assert fast == small + bh * tiles * 2048                                                    # the whole launch in one chunk here
-    assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 0, 1)) == small        # a mask / dropout: no hand-over
-    if nq != nk:
-        assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 1, 0)) == small    # nor under the causal mask
-    o, lse = ext.ex_forward(qd, kd, vd, False, scale)
+    assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, int(causal), 1)) == small        # a mask / dropout: no hand-over
+    if nq > nk:
+        assert int(lib.fa_ex_backward_workspace_bytes_fast(bh, nq, nk, d, 2, 1, 0)) == small    # causal with Nk < Nq: not on these kernels
+    o, lse = ext.ex_forward(qd, kd, vd, causal, scale)
     ext.release_workspace()
     ext.profile_enable(True)
-    grads = ext.ex_backward(qd, kd, vd, o, dod, lse, False, scale)
+    grads = ext.ex_backward(qd, kd, vd, o, dod, lse, causal, scale)
     torch.cuda.synchronize()
     prof = ext.profile_report()
     ext.profile_enable(False)
@@ -361,7 +362,7 @@ def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
     ext.set_option("dq", 5)
     try:
         ext.profile_enable(True)
-        ref = ext.ex_backward(qd, kd, vd, o, dod, lse, False, scale)
+        ref = ext.ex_backward(qd, kd, vd, o, dod, lse, causal, scale)
         torch.cuda.synchronize()
         prof5 = ext.profile_report()
         ext.profile_enable(False)
@@ -370,12 +371,12 @@ def test_plain_calls_hand_ds_over_on_the_extended_path_too(nq, nk, device):
     assert "bwd_delta" not in prof5, prof5
     for a, b in zip(grads, ref):
         assert torch.isfinite(a.float()).all() and max_abs(a, b) <= 2e-2 * max(1.0, float(b.float().abs().max()))
-    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q[:2], k[:2], v[:2], do[:2], causal=False, softmax_scale=scale)
+    rq, rk, rv, ro, rlse = orc.extended_attention_backward(q[:2], k[:2], v[:2], do[:2], causal=causal, softmax_scale=scale)
     tol = dtype_tolerances(torch.bfloat16)
     for a, b in zip(grads, (rq, rk, rv)):
         torch.testing.assert_close(a[:2].cpu(), b, **tol)
     # and the last unit (the chunk loop's offsets into the key-side tensors)
-    rq2, rk2, rv2, _, _ = orc.extended_attention_backward(q[-1:], k[-1:], v[-1:], do[-1:], causal=False, softmax_scale=scale)
+    rq2, rk2, rv2, _, _ = orc.extended_attention_backward(q[-1:], k[-1:], v[-1:], do[-1:], causal=causal, softmax_scale=scale)
     for a, b in zip(grads, (rq2, rk2, rv2)):
         torch.testing.assert_close(a[-1:].cpu(), b, **tol)
     ext.release_workspace()
