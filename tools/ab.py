@@ -16,7 +16,7 @@ VARIANTS = [   # edit to taste: every key of ALL_KEYS is an fa_set_option name (
     ("fwd: lock-step kernel", {"fwd_stag": 2}),
     ("fwd: staggered kernel, 64-key tiles", {"fwd_stag": 1}),
 ]
-ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "fwd_rd", "fwd_w2", "dkdv_kreg"]
+ALL_KEYS = ["fwd_kb", "fwd_stag", "dkdv", "dq_kt", "fwd_rs", "dkdv_kreg", "fwd_eager", "fwd_hs", "fwd_tpw", "dq_tpw", "dkdv_tpw", "dq_nlf", "dq_w4", "fwd_abl", "small_grid", "fp8_rot", "dkdv_stg", "fwd_rd", "fwd_w2", "dkdv_abl", "dq", "dq_abl", "ds_chunk_mb"]
 
 
 def main():
